@@ -1,0 +1,373 @@
+"""ORACLE -- CPU restatement of the reference's M3AE Med-VQA hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; it is the
+checker, never the product.  Plain PyTorch-CPU fp32 tensor algebra (matmul / softmax / mean / erf),
+written as pure functions over a state_dict whose key names and shapes are the reference's
+(SURVEY.md 8b "Weights").  Gradients come from torch autograd over these functions.
+
+Parity pin: this restatement is checked against fixtures produced by importing and running the
+reference's own modules in the build container (oracle/make_golden.py -> tests/golden/*.npz;
+tests/test_oracle_golden.py).  Third-party arithmetic the reference calls into (transformers==4.6.0
+RobertaModel, torch 1.9 nn.MultiheadAttention) is pinned by the container's transformers 5.15 /
+torch 2.10 implementations of the same math.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def linear(sd, prefix, x):
+    return x @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
+
+
+def layer_norm(sd, prefix, x, eps):
+    """nn.LayerNorm (biased variance, eps inside the sqrt).  clip_model.py:27-33 computes it in
+    fp32 and casts back; in this all-fp32 oracle that is the identity."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * sd[prefix + ".weight"] + sd[prefix + ".bias"]
+
+
+def gelu_erf(x):
+    """ACT2FN["gelu"] (bert_model.py:421) and nn.GELU() (m3ae_module.py:123): exact erf form."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def quick_gelu(x):
+    """clip_model.py:36-38."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def extended_mask(mask):
+    """transformers 4.6.0 get_extended_attention_mask as called at m3ae_module.py:232,255:
+    (1 - mask)[:, None, None, :] * -10000.0 (additive, NOT -inf)."""
+    return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+
+
+def split_heads(x, heads):
+    B, L, D = x.shape
+    return x.view(B, L, heads, D // heads).permute(0, 2, 1, 3)
+
+
+def merge_heads(x):
+    B, H, L, dh = x.shape
+    return x.permute(0, 2, 1, 3).reshape(B, L, H * dh)
+
+
+def sdpa(q, k, v, add_mask):
+    """bert_model.py:301-340: scores = QK^T / sqrt(dh) + mask; softmax; PV."""
+    dh = q.shape[-1]
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if add_mask is not None:
+        s = s + add_mask
+    p = torch.softmax(s, dim=-1)
+    return p @ v
+
+
+# ------------------------------------------------------------------------------------------------
+# BERT / RoBERTa blocks (bert_model.py:211-503; identical math in HF RobertaLayer)
+# ------------------------------------------------------------------------------------------------
+def bert_attention(sd, prefix, h, kv, add_mask, heads, eps):
+    """BertAttention (bert_model.py:367-413) = BertSelfAttention (:253-350) + BertSelfOutput (:360-364).
+    `kv` is `h` for self-attention, the other stream for cross-attention (:275-278); the residual is `h`."""
+    q = split_heads(linear(sd, prefix + ".self.query", h), heads)
+    k = split_heads(linear(sd, prefix + ".self.key", kv), heads)
+    v = split_heads(linear(sd, prefix + ".self.value", kv), heads)
+    ctx = merge_heads(sdpa(q, k, v, add_mask))
+    out = linear(sd, prefix + ".output.dense", ctx)
+    return layer_norm(sd, prefix + ".output.LayerNorm", out + h, eps)
+
+
+def bert_ffn(sd, prefix, h, eps):
+    """BertIntermediate (:416-428) + BertOutput (:431-442), feed_forward_chunk (:500-503)."""
+    u = gelu_erf(linear(sd, prefix + ".intermediate.dense", h))
+    out = linear(sd, prefix + ".output.dense", u)
+    return layer_norm(sd, prefix + ".output.LayerNorm", out + h, eps)
+
+
+def bert_cross_layer(sd, prefix, h, other, mask_self, mask_other, heads, eps=1e-12):
+    """BertCrossLayer.forward (bert_model.py:457-498): self-attn -> cross-attn (residual = self-attn
+    output) -> FFN.  eps = RobertaConfig default 1e-12 (m3ae_module.py:24-33)."""
+    a = bert_attention(sd, prefix + ".attention", h, h, mask_self, heads, eps)
+    c = bert_attention(sd, prefix + ".crossattention", a, other, mask_other, heads, eps)
+    return bert_ffn(sd, prefix, c, eps)
+
+
+def roberta_layer(sd, prefix, h, add_mask, heads, eps=1e-5):
+    """HF RobertaLayer (third party, called at m3ae_module.py:233-234): post-LN self-attn + FFN."""
+    a = bert_attention(sd, prefix + ".attention", h, h, add_mask, heads, eps)
+    return bert_ffn(sd, prefix, a, eps)
+
+
+def roberta_embeddings(sd, prefix, ids, pad_id=1, eps=1e-5):
+    """HF RobertaEmbeddings (third party; m3ae_module.py:230): position ids =
+    cumsum(ids != pad) * (ids != pad) + pad; word + type[0] + pos; LayerNorm(1e-5)."""
+    ne = (ids != pad_id).long()
+    pos = torch.cumsum(ne, dim=1) * ne + pad_id
+    e = (sd[prefix + ".word_embeddings.weight"][ids]
+         + sd[prefix + ".token_type_embeddings.weight"][torch.zeros_like(ids)]
+         + sd[prefix + ".position_embeddings.weight"][pos])
+    return layer_norm(sd, prefix + ".LayerNorm", e, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP ViT (clip_model.py:41-128)
+# ------------------------------------------------------------------------------------------------
+def clip_block(sd, prefix, x, heads):
+    """ResidualAttentionBlock.forward (clip_model.py:60-63), nn.MultiheadAttention with packed
+    in_proj_weight [3d, d] (rows Q, K, V), q scaled by 1/sqrt(dh) before QK^T (torch 1.9), no mask."""
+    d = x.shape[-1]
+    h = layer_norm(sd, prefix + ".ln_1", x, 1e-5)
+    qkv = h @ sd[prefix + ".attn.in_proj_weight"].t() + sd[prefix + ".attn.in_proj_bias"]
+    q, k, v = qkv.split(d, dim=-1)
+    ctx = merge_heads(sdpa(split_heads(q, heads), split_heads(k, heads), split_heads(v, heads), None))
+    x = x + linear(sd, prefix + ".attn.out_proj", ctx)
+    h = layer_norm(sd, prefix + ".ln_2", x, 1e-5)
+    h = quick_gelu(linear(sd, prefix + ".mlp.c_fc", h))
+    return x + linear(sd, prefix + ".mlp.c_proj", h)
+
+
+def clip_patch_embed(sd, prefix, img):
+    """VisualTransformer.forward_patch_embed (clip_model.py:110-116): conv k=s=patch, no bias ->
+    [B, grid^2, width] row-major (h then w) -> prepend class_embedding."""
+    w = sd[prefix + ".conv1.weight"]
+    x = F.conv2d(img, w, stride=w.shape[-1])
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    cls = sd[prefix + ".class_embedding"].view(1, 1, -1).expand(x.shape[0], 1, -1)
+    return torch.cat([cls, x], dim=1)
+
+
+def clip_trans(sd, prefix, x, heads):
+    """forward_trans (clip_model.py:122-128): ln_pre -> (layers-1) blocks (:71) -> ln_post; no proj."""
+    x = layer_norm(sd, prefix + ".ln_pre", x, 1e-5)
+    i = 0
+    while f"{prefix}.transformer.resblocks.{i}.ln_1.weight" in sd:
+        x = clip_block(sd, f"{prefix}.transformer.resblocks.{i}", x, heads)
+        i += 1
+    return layer_norm(sd, prefix + ".ln_post", x, 1e-5)
+
+
+def clip_visual(sd, prefix, img, heads):
+    """VisualTransformer.forward (clip_model.py:93-108)."""
+    x = clip_patch_embed(sd, prefix, img)
+    x = x + sd[prefix + ".positional_embedding"]
+    return clip_trans(sd, prefix, x, heads)
+
+
+# ------------------------------------------------------------------------------------------------
+# MIM helpers (m3ae_module.py:153-192)
+# ------------------------------------------------------------------------------------------------
+def random_masking(sd, x, mask_ratio, noise):
+    """m3ae_module.py:153-183 with the U(0,1) `noise` [B, L] supplied by the caller."""
+    x_, x = x[:, :1], x[:, 1:]
+    pos = sd["vision_encoder.visual.positional_embedding"].unsqueeze(0)
+    N, L, D = x.shape
+    len_keep = int(L * (1 - mask_ratio))
+    ids_shuffle = torch.argsort(noise, dim=1)
+    ids_restore = torch.argsort(ids_shuffle, dim=1)
+    ids_keep = ids_shuffle[:, :len_keep]
+    x = x + pos[:, 1:]
+    x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).repeat(1, 1, D))
+    mask = torch.ones(N, L)
+    mask[:, :len_keep] = 0
+    mask = torch.gather(mask, 1, ids_restore)
+    x_masked = torch.cat((x_ + pos[:, :1], x_masked), dim=1)
+    return x_masked, mask, ids_restore
+
+
+def patchify(imgs, p):
+    """m3ae_module.py:185-192: nchpwq -> nhwpqc."""
+    h = w = imgs.shape[2] // p
+    x = imgs.reshape(imgs.shape[0], 3, h, p, w, p)
+    x = torch.einsum("nchpwq->nhwpqc", x)
+    return x.reshape(imgs.shape[0], h * w, p * p * 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# M3AETransformerSS.infer (m3ae_module.py:203-312) and heads
+# ------------------------------------------------------------------------------------------------
+def pooler(sd, prefix, h):
+    """prediction_heads.py:9-19."""
+    return torch.tanh(linear(sd, prefix + ".dense", h[:, 0]))
+
+
+def infer(sd, cfg, img, text_ids, text_masks, mim_noise=None, trail=None):
+    """M3AETransformerSS.infer (m3ae_module.py:203-312), eval mode (no dropout).
+    cfg: dict(num_heads, vit_heads, text_heads, num_top_layer, patch_size, mim_prob, mim_layer).
+    If `mim_noise` is given, runs the mask_image=True branch (:239-249)."""
+    ret = {}
+    H, Hv, Ht = cfg["num_heads"], cfg["vit_heads"], cfg["text_heads"]
+    # text (m3ae_module.py:230-235)
+    t = roberta_embeddings(sd, "language_encoder.embeddings", text_ids)
+    mt = extended_mask(text_masks)
+    i = 0
+    while f"language_encoder.encoder.layer.{i}.attention.self.query.weight" in sd:
+        t = roberta_layer(sd, f"language_encoder.encoder.layer.{i}", t, mt, Ht)
+        i += 1
+    if trail is not None:
+        trail["text_enc"] = t
+    t = linear(sd, "multi_modal_language_proj", t)
+    # image (m3ae_module.py:239-256)
+    if mim_noise is not None:
+        v = clip_patch_embed(sd, "vision_encoder.visual", img)
+        v, mim_masks, ids_restore = random_masking(sd, v, cfg["mim_prob"], mim_noise)
+        v = clip_trans(sd, "vision_encoder.visual", v, Hv)
+        ret["mim_masks"], ret["mim_ids_restore"] = mim_masks, ids_restore
+    else:
+        v = clip_visual(sd, "vision_encoder.visual", img, Hv)
+    if trail is not None:
+        trail["image_enc"] = v
+    v = linear(sd, "multi_modal_vision_proj", v)
+    mv = torch.zeros(v.shape[0], 1, 1, v.shape[1])  # all-ones mask -> additive zeros (:253-256)
+    # type embeddings (m3ae_module.py:260-263)
+    t = t + sd["modality_type_embeddings.weight"][0]
+    v = v + sd["modality_type_embeddings.weight"][1]
+    # fusion (m3ae_module.py:269-278): both streams read the PRE-update x, y
+    x, y = t, v
+    for l in range(cfg["num_top_layer"]):
+        if mim_noise is not None and cfg.get("mim_layer", -1) == l:
+            ret[f"multi_modal_text_feats_{l}"], ret[f"multi_modal_image_feats_{l}"] = x, y
+        x1 = bert_cross_layer(sd, f"multi_modal_language_layers.{l}", x, y, mt, mv, H)
+        y1 = bert_cross_layer(sd, f"multi_modal_vision_layers.{l}", y, x, mv, mt, H)
+        x, y = x1, y1
+        if trail is not None:
+            trail[f"fusion_text_{l}"], trail[f"fusion_image_{l}"] = x, y
+    # pool (m3ae_module.py:288-296)
+    cls = torch.cat([pooler(sd, "multi_modal_language_pooler", x), pooler(sd, "multi_modal_vision_pooler", y)], -1)
+    ret.update(multi_modal_text_feats=x, multi_modal_image_feats=y, multi_modal_cls_feats=cls,
+               extended_text_masks=mt, extended_image_masks=mv)
+    return ret
+
+
+def vqa_head(sd, cls):
+    """m3ae_module.py:118-126: Linear -> LayerNorm(1e-5) -> GELU(erf) -> Linear."""
+    h = linear(sd, "vqa_head.0", cls)
+    h = gelu_erf(layer_norm(sd, "vqa_head.1", h, 1e-5))
+    return linear(sd, "vqa_head.3", h)
+
+
+def vqa_targets(vqa_labels, vqa_scores, label_size):
+    """objectives.py:188-197."""
+    t = torch.zeros(len(vqa_labels), label_size)
+    for i, (ls, ss) in enumerate(zip(vqa_labels, vqa_scores)):
+        for l, s in zip(ls, ss):
+            t[i, l] = s
+    return t
+
+
+def vqa_loss(logits, targets):
+    """objectives.py:201: BCEWithLogits(mean over all elements) * num_labels."""
+    x, z = logits, targets
+    per = torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-x.abs()))
+    return per.mean() * targets.shape[1]
+
+
+def training_loss(sd, cfg, batch):
+    """training_step for loss_names = {vqa: 1} (m3ae_module.py:347-353 -> objectives.py:176-201)."""
+    out = infer(sd, cfg, batch["image"][0], batch["text_ids"], batch["text_masks"])
+    logits = vqa_head(sd, out["multi_modal_cls_feats"])
+    tgt = vqa_targets(batch["vqa_labels"], batch["vqa_scores"], logits.shape[1])
+    return vqa_loss(logits, tgt), logits, out
+
+
+# ------------------------------------------------------------------------------------------------
+# pretraining heads / losses (prediction_heads.py:22-96; objectives.py:14-119)
+# ------------------------------------------------------------------------------------------------
+def mlm_head(sd, x, eps=1e-12):
+    """MLMHead (prediction_heads.py:22-34): BertPredictionHeadTransform (dense + gelu + LN) ->
+    decoder (no bias) + bias."""
+    h = gelu_erf(linear(sd, "mlm_head.transform.dense", x))
+    h = layer_norm(sd, "mlm_head.transform.LayerNorm", h, eps)
+    return h @ sd["mlm_head.decoder.weight"].t() + sd["mlm_head.bias"]
+
+
+def mlm_loss(logits, labels):
+    """objectives.py:19-23: CE with ignore_index=-100, mean over non-ignored."""
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100)
+
+
+def mim_head(sd, x, ids_restore, heads):
+    """MIMHead.forward (prediction_heads.py:60-86); decoder = Transformer(layers+1) -> layers blocks."""
+    x = linear(sd, "mim_head.decoder_embed", x)
+    n_mask = ids_restore.shape[1] + 1 - x.shape[1]
+    mt = sd["mim_head.mask_token"].repeat(x.shape[0], n_mask, 1)
+    x_ = torch.cat([x[:, 1:], mt], dim=1)
+    x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))
+    x = torch.cat([x[:, :1], x_], dim=1)
+    x = x + sd["mim_head.decoder_pos_embed"]
+    i = 0
+    while f"mim_head.decoder.resblocks.{i}.ln_1.weight" in sd:
+        x = clip_block(sd, f"mim_head.decoder.resblocks.{i}", x, heads)
+        i += 1
+    x = layer_norm(sd, "mim_head.decoder_norm", x, 1e-5)
+    x = linear(sd, "mim_head.decoder_pred", x)
+    return x[:, 1:]
+
+
+def mim_loss(pred, img, mask, patch, norm_pix=True):
+    """objectives.py:52-62: per-patch normalised target (UNBIASED var + 1e-6), MSE on masked patches."""
+    target = patchify(img, patch)
+    if norm_pix:
+        mean = target.mean(-1, keepdim=True)
+        var = target.var(-1, keepdim=True)
+        target = (target - mean) / (var + 1e-6) ** 0.5
+    l = ((pred - target) ** 2).mean(-1)
+    return (l * mask).sum() / mask.sum()
+
+
+def itm_head(sd, cls):
+    """ITMHead (prediction_heads.py:89-96)."""
+    return linear(sd, "itm_head.fc", cls)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer / schedule (m3ae_utils.py:112-242)
+# ------------------------------------------------------------------------------------------------
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight",
+            "norm1.bias", "norm1.weight", "norm2.bias", "norm2.weight"]
+HEAD_NAMES = ["mlm_head", "mim_head", "itm_head", "vqa_head", "cls_head", "irtr_head"]
+
+
+def param_group_of(name):
+    """Index 0..5 of the six groups of m3ae_utils.py:135-204 (substring matches on the name)."""
+    nd = any(k in name for k in NO_DECAY)
+    hd = any(k in name for k in HEAD_NAMES)
+    mm = "multi_modal" in name
+    if not hd and not mm:
+        return 1 if nd else 0
+    if hd and not mm:
+        return 3 if nd else 2
+    if mm and not hd:
+        return 5 if nd else 4
+    return -1  # head AND multi_modal: in no group (the reference silently drops such params)
+
+
+def poly_lr_factor(step, warmup_steps, max_steps, lr_init, lr_end=0.0, power=1.0):
+    """transformers get_polynomial_decay_schedule_with_warmup (called at m3ae_utils.py:232-238)."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    if step > max_steps:
+        return lr_end / lr_init
+    lr_range = lr_init - lr_end
+    decay_steps = max_steps - warmup_steps
+    pct_remaining = 1 - (step - warmup_steps) / decay_steps
+    return (lr_range * pct_remaining ** power + lr_end) / lr_init
+
+
+def adamw_step(p, g, m, v, step, lr, wd, beta1=0.9, beta2=0.98, eps=1e-8):
+    """transformers 4.6.0 AdamW.step (m3ae_utils.py:206): bias-corrected Adam update, then decoupled
+    weight decay p -= lr * wd * p applied AFTER the update.  `step` counts from 1.  In place."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    p.addcdiv_(m, denom, value=-step_size)
+    if wd > 0:
+        p.add_(p, alpha=-lr * wd)
+    return p
