@@ -1,0 +1,185 @@
+/*
+ * m3ae_hip.h -- C ABI of libm3ae_hip.so: the MI355X (gfx950) kernels behind the M3AE Med-VQA hot path.
+ *
+ * The reference (better62/MM-VQA-Healthcare) is 100 % Python: it has no FFI / plugin interface for this path.
+ * Its boundary is the nn.Module tree of M3AETransformerSS (m3ae/modules/m3ae_module.py:16) whose blocks call
+ * PyTorch ATen ops.  Each entry point below replaces the ATen call chain of one reference code site (cited per
+ * function); the Python modules in mm-vqa-healthcare_amd/m3ae_amd/modules/ keep the reference's module / parameter
+ * names and call these entry points through ctypes (m3ae_amd/_lib.py).  See INTEGRATION.md for the binding stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless noted.
+ *   - Every function is stream-ordered on `stream` (a hipStream_t passed as void*), never synchronises the host,
+ *     allocates nothing and keeps no mutable global state; the caller owns every buffer incl. workspaces.
+ *   - Return value: 0 = ok; M3AE_ERR_* (negative) = rejected before launch; positive = hipError_t of the launch.
+ *   - dtype: activations are M3AE_BF16 ("perf mode") or M3AE_F32 ("parity mode"); parameters that are vectors
+ *     (biases, LayerNorm scale/shift), embedding tables, masks, statistics and gradients of parameters are fp32.
+ */
+#ifndef M3AE_HIP_H
+#define M3AE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3AE_ABI_VERSION 1
+
+enum { M3AE_F32 = 0, M3AE_BF16 = 1 };
+enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TANH = 3, M3AE_ACT_RELU = 4 };
+enum { M3AE_ERR_ARG = -1, M3AE_ERR_UNSUPPORTED = -2, M3AE_ERR_ALIGN = -3, M3AE_ERR_WORKSPACE = -4 };
+
+int m3ae_abi_version(void);
+/* name of the kernel family the last m3ae_gemm call on this thread dispatched to ("mfma_nt", "mfma_tn", "generic") */
+const char* m3ae_last_gemm_path(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.  Replaces nn.Linear / torch.matmul / F.conv2d(k=s=patch) call sites:
+ *   clip_model.py:44,47-49,58,94 (packed in-proj, out-proj, c_fc, c_proj, patch-embed conv as GEMM);
+ *   bert_model.py:224-226,263,276-277,356,361,419,426,434,439 (Q/K/V, attention output, intermediate, output);
+ *   m3ae_module.py:70-73,120-125,235,252 (modality projections, vqa_head); prediction_heads.py:12,17 (Pooler);
+ *   and their autograd backward (dgrad / wgrad).
+ *
+ *   C[b1][b2][m][n] = epi( alpha * sum_k A[b1][b2][m][k] * B[b1][b2][k][n] )
+ *   epi(x): x += bias[n]; if (preact) preact[m][n] = x; x = act(x); if (residual) x += residual[m][n];
+ *           if (dact_aux) x *= act'(dact_aux[m][n]) (derivative of `dact` at the saved pre-activation);
+ *           if (accumulate) C += x else C = x.
+ * Strides are in ELEMENTS.  preact / residual / dact_aux share C's strides and dtype.
+ * Dispatch: bf16 A,B with K-contiguous operands (a_sk == b_sk == 1) -> MFMA "NT" kernel;
+ *           bf16 A,B with reduction-strided operands (a_sm == b_sn == 1), fp32 C, accumulate -> MFMA "TN" (wgrad)
+ *           kernel with split-K fp32 atomics; anything else (fp32 operands, odd shapes, batched) -> generic kernel.
+ */
+typedef struct {
+    int64_t M, N, K;
+    int64_t batch1, batch2;
+    const void* A; int64_t a_sm, a_sk, a_sb1, a_sb2;
+    const void* B; int64_t b_sk, b_sn, b_sb1, b_sb2;
+    void* C;       int64_t c_sm, c_sn, c_sb1, c_sb2;
+    int32_t dtype_a, dtype_b, dtype_c;
+    float alpha;
+    int32_t accumulate;
+    const float* bias;
+    int32_t act;
+    void* preact;
+    const void* residual;
+    const void* dact_aux;
+    int32_t dact;
+    int32_t force_generic; /* tests: bypass the MFMA kernels */
+} m3ae_gemm_desc;
+int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention, forward and backward (flash-style in bf16, materialised in fp32).
+ * Replaces bert_model.py:301-340 (QK^T / sqrt(dh) + additive mask, softmax, PV) for self- and cross-attention in
+ * BertCrossLayer / RobertaLayer, and torch-1.9 F.multi_head_attention_forward's bmm-softmax-bmm in
+ * clip_model.py:58; with pos_bias also HF T5Attention (called from m3ae_t5_mm_encoder_input.py:202,244).
+ *   q [B, Lq, H*Dh], k / v [B, Lk, H*Dh] with explicit batch and token strides (head h at element offset h*Dh, Dh
+ *   contiguous), so packed QKV buffers are addressed in place.  o like q.
+ *   key_mask: additive fp32 [B, Lk] (the reference's (1-mask)*-10000.0 extended mask, m3ae_module.py:232) or NULL.
+ *   pos_bias: additive fp32 [H, Lq, Lk] or NULL.  lse: fp32 [B, H, lse_stride] (lse_stride >= Lq, multiple of 32).
+ *   Dh must be 64 for the bf16 kernels.  workspace: see m3ae_attn_workspace_bytes (fp32 path only).
+ */
+typedef struct {
+    int64_t B, H, Lq, Lk, Dh;
+    const void* q; int64_t q_sb, q_sl;
+    const void* k; int64_t k_sb, k_sl;
+    const void* v; int64_t v_sb, v_sl;
+    void* o;       int64_t o_sb, o_sl;
+    const float* key_mask;
+    const float* pos_bias;
+    float scale;
+    int32_t causal;
+    float* lse; int64_t lse_stride;
+    int32_t dtype;
+    void* workspace; int64_t workspace_bytes;
+    /* backward only */
+    const void* d_o;               /* layout of o */
+    void* dq; void* dk; void* dv;  /* layouts of q, k, v */
+    float* delta;                  /* fp32 [B, H, lse_stride] scratch: rowsum(dO * O) */
+    float* d_pos_bias;             /* fp32 [H, Lq, Lk], accumulated; or NULL */
+} m3ae_attn_desc;
+int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward);
+int m3ae_attn_fwd(const m3ae_attn_desc* d, void* stream);
+int m3ae_attn_bwd(const m3ae_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LayerNorm (biased variance, eps inside the sqrt, fp32 statistics), optional fused activation on the output.
+ * Replaces nn.LayerNorm at bert_model.py:357,363,435,441 (eps 1e-12 / 1e-5), clip_model.py:27-33 (fp32 upcast),
+ * m3ae_module.py:122 (+ nn.GELU :123 via `act`).  mean / rstd: fp32 [M] saved for backward.
+ * bwd: dx = LN'(dy); dgamma / dbeta are ACCUMULATED (+=) in fp32.  workspace: fp32 [2 * nblk * D] with
+ * nblk = m3ae_layernorm_bwd_blocks(M).  rms != 0 selects T5 RMSNorm (no mean subtraction, no beta).
+ */
+int m3ae_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int64_t M, int64_t D, float eps, int dtype, int act, int rms, void* stream);
+int64_t m3ae_layernorm_bwd_blocks(int64_t M);
+int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t M,
+                       int64_t D, int dtype, int act, int rms, void* stream);
+
+/* out[n] (+)= sum_m x[m][n]  (bias gradients; x has row stride ldx elements). */
+int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * RoBERTa embeddings (HF RobertaEmbeddings called at m3ae_module.py:230): position ids =
+ * cumsum(ids != pad) * (ids != pad) + pad; out = word[ids] + type[0] + pos[position id]  (LayerNorm is a separate
+ * call).  Tables are the fp32 master parameters.  bwd scatter-adds d_out into the fp32 table gradients.
+ */
+int m3ae_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type, void* out,
+                           int64_t B, int64_t S, int64_t D, int64_t pad_id, int dtype, void* stream);
+int m3ae_roberta_embed_bwd(const int64_t* ids, const void* d_out, float* d_word, float* d_pos, float* d_type,
+                           int64_t B, int64_t S, int64_t D, int64_t pad_id, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ViT token assembly (clip_model.py:94-99): im2col of non-overlapping patches (column order c, ph, pw = the
+ * row-major flattening of conv1.weight[width, 3, P, P]) and [cls | patches] + positional_embedding.
+ */
+int m3ae_patchify(const float* img, void* out, int64_t B, int64_t R, int64_t P, int dtype, void* stream);
+int m3ae_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* out, int64_t B, int64_t G,
+                        int64_t D, int dtype, void* stream);
+int m3ae_vit_tokens_bwd(const void* d_out, void* d_patch, float* d_cls, float* d_pos, int64_t B, int64_t G,
+                        int64_t D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses.  bce: objectives.py:201  loss = mean(BCEWithLogits(x, z)) * C.  Writes loss[0] (fp32, overwritten) and
+ * d_logits = d(loss)/dx * grad_scale.  xent: F.cross_entropy(ignore_index=-100, mean) (objectives.py:19-23,101).
+ */
+int m3ae_bce_logits(const void* logits, const float* targets, float* loss, void* d_logits, int64_t B, int64_t C,
+                    float grad_scale, int dtype, void* stream);
+int m3ae_xent(const void* logits, const int64_t* labels, float* loss, void* d_logits, float* workspace,
+              int64_t rows, int64_t C, int64_t ld, float grad_scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * AdamW as transformers==4.6.0 implements it (m3ae_utils.py:206): bias-corrected Adam update, then decoupled
+ * decay p -= lr * wd * p.  One call per contiguous fp32 segment (a parameter group of the flat buffer).
+ * g is multiplied by grad_scale first (1 / world_size for DDP averaging).  If shadow != NULL also writes the bf16
+ * copy used by the forward pass.
+ */
+int m3ae_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+               float beta2, float eps, float wd, int64_t step, float grad_scale, void* stream);
+
+/* bf16 [R, C] <- fp32 [R, C] cast; and the transposed bf16 copy out_t [C, R] (dgrad operand). either may be NULL */
+int m3ae_cast_transpose(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream);
+/* elementwise: out = cast(in) (dtype_in -> dtype_out), n elements */
+int m3ae_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
+/* out = a + b (same dtype) */
+int m3ae_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* dx = dy * act'(x_pre) ; y = act(x) standalone forms */
+int m3ae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+int m3ae_act_bwd(const void* dy, const void* x_pre, void* dx, int64_t n, int act, int dtype, void* stream);
+/* rows gather / scatter-add along dim 0 of a [R, D] matrix: out[i] = in[idx[i]] ; d_in[idx[i]] += d_out[i]
+ * (MIM masking, m3ae_module.py:170; prediction_heads.py:68). */
+int m3ae_gather_rows(const void* in, const int64_t* idx, void* out, int64_t n_out, int64_t D, int dtype,
+                     void* stream);
+int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void* d_in, int64_t n_out, int64_t D, int dtype,
+                          void* stream);
+
+/* self-test of hardware idioms the kernels rely on (MFMA fragment maps, ds_read_b64_tr_b16, accumulator-as-
+ * operand k-order).  out: int32[8] device buffer, out[0] = number of mismatches. */
+int m3ae_selftest(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3AE_HIP_H */

@@ -1,0 +1,594 @@
+// Scaled-dot-product attention for the M3AE hot path (self 577x577, text 32x32, cross 32x577 / 577x32; Dh = 64).
+//
+// bf16 ("perf mode"): flash-style, nothing of size Lq x Lk ever reaches HBM.
+//   One wave owns one 32-row tile and streams 32-row tiles of the other side.  Products use
+//   v_mfma_f32_32x32x16_bf16 with the streamed index on the accumulator ROWS ("swapped" S^T = K.Q^T), so that
+//     * the softmax reduction over keys is in-lane (16 registers) + one exchange with lane^32,
+//     * the bf16-converted accumulator is directly the B operand of the next product (O^T = V^T.P^T): no LDS
+//       round trip for P (cdna_hip_programming.md 3 "An accumulator tile as the next MFMA's operand"),
+//     * the only operand that needs a transpose (V^T, K^T, Q^T, dO^T fragments: 4 consecutive rows per lane) is
+//       read from a small per-wave LDS tile with the transposing read ds_read_b64_tr_b16.
+//   Row-major fragments (8 consecutive d per lane) come straight from global/L2 as 16-byte loads.
+//   Waves never synchronise with each other (per-wave LDS regions, no barriers).
+//   Backward is two kernels in the same mould (dQ: wave = 32 queries; dK/dV: wave = 32 keys), recomputing P from
+//   the saved log-sum-exp: deterministic, no atomics.
+// fp32 ("parity mode"): the reference's own algorithm (bert_model.py:301-340): S = QK^T/sqrt(dh) + mask
+//   materialised in a caller workspace, row softmax, PV, through the generic GEMM kernel.
+#include "common.h"
+
+int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int VRS = 192;  // LDS row stride (bytes) of a [32][64] bf16 tile: 4 consecutive rows hit 4 disjoint bank quarters
+constexpr int TILE_LDS = 32 * VRS;
+
+struct AttnArgs {
+    const bf16_t* q; int64_t q_sb, q_sl;
+    const bf16_t* k; int64_t k_sb, k_sl;
+    const bf16_t* v; int64_t v_sb, v_sl;
+    bf16_t* o; int64_t o_sb, o_sl;
+    const float* key_mask;
+    const float* pos_bias;
+    float scale, scale_log2;
+    int causal;
+    float* lse; int64_t lse_stride;
+    int64_t B, H, Lq, Lk;
+    const bf16_t* d_o;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    float* delta;
+    float* d_pos_bias;
+};
+
+DEVINL f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                   0, 0, 0);
+}
+
+// accumulator register `reg` of lane half `h` holds ROW crow(reg, h) of a 32x32 tile (column = lane & 31)
+DEVINL int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// bf16 B-operand fragment for k-step s from accumulator registers 8s..8s+7 (k order = crow order)
+DEVINL s16x8 pack_acc(const f32x16& p, int s) {
+    u32x4 w;
+    w[0] = pack2bf(p[8 * s + 0], p[8 * s + 1]);
+    w[1] = pack2bf(p[8 * s + 2], p[8 * s + 3]);
+    w[2] = pack2bf(p[8 * s + 4], p[8 * s + 5]);
+    w[3] = pack2bf(p[8 * s + 6], p[8 * s + 7]);
+    return __builtin_bit_cast(s16x8, w);
+}
+
+// 16-byte row fragment: row-major [row][64] bf16 operand, element j <-> d = 16 * ks + 8 * h + j
+DEVINL s16x8 row_frag(const bf16_t* rowp, int ks, int h) { return *(const s16x8*)(rowp + 16 * ks + 8 * h); }
+
+// Stage a [32 rows][64 d] tile (rows row0.., clamped to nrows-1) into this wave's LDS tile: 4 x 16 B per lane.
+struct Stage4 { s16x8 v[4]; };
+DEVINL Stage4 tile_load(const bf16_t* base, int64_t sl, int64_t row0, int64_t nrows, int lane) {
+    Stage4 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        int64_t row = row0 + (c >> 3);
+        row = row < nrows ? row : nrows - 1;
+        s.v[i] = *(const s16x8*)(base + row * sl + (c & 7) * 8);
+    }
+    return s;
+}
+DEVINL void tile_store(char* tile, const Stage4& s, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        *(s16x8*)(tile + (c >> 3) * VRS + (c & 7) * 16) = s.v[i];
+    }
+}
+
+// Transposed A-operand fragment from a [32 rows][64 d] LDS tile: MFMA row index = d = 32 * dt + (lane & 31),
+// element j <-> tile row 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)   (= crow order of pack_acc).
+DEVINL s16x8 tr_frag(const char* tile, int dt, int s, int lane) {
+    const int h = lane >> 5, gg = (lane >> 4) & 1, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+    const int row = 16 * s + 4 * h + qq;
+    const int dcol = 32 * dt + 16 * gg + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + row * VRS + dcol * 2));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (row + 8) * VRS + dcol * 2));
+    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// Store a transposed accumulator pair (O^T / dQ^T / dK^T / dV^T: rows = d, column = lane's token) as [token][64].
+DEVINL void store_rows(bf16_t* rowp, const f32x16& t0, const f32x16& t1, float mul, int h) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& t = dt ? t1 : t0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            u32x2 w;
+            w[0] = pack2bf(t[4 * g4 + 0] * mul, t[4 * g4 + 1] * mul);
+            w[1] = pack2bf(t[4 * g4 + 2] * mul, t[4 * g4 + 3] * mul);
+            *(u32x2*)(rowp + 32 * dt + 8 * g4 + 4 * h) = w;
+        }
+    }
+}
+
+DEVINL f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t q0 = qt * 32;
+    if (q0 >= a.Lq) return;  // whole wave; no barriers in this kernel
+    char* tile = lds + wave * TILE_LDS;
+
+    const int64_t qi = q0 + r;
+    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
+    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+    s16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_frag(qp, ks, h);
+
+    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
+    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
+    const float* mrow = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
+    const float* brow = a.pos_bias ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+
+    f32x16 o0 = zero16(), o1 = zero16();
+    float m = -1e30f, l = 0.f;
+    const int nkt = (int)((a.Lk + 31) / 32);
+
+    s16x8 kf_n[4];
+    {
+        const int64_t kr = r < a.Lk ? r : a.Lk - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+    }
+    Stage4 vs_n = tile_load(vbase, a.v_sl, 0, a.Lk, lane);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        s16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = kf_n[ks];
+        asm volatile("" ::: "memory");
+        tile_store(tile, vs_n, lane);
+        if (kt + 1 < nkt) {
+            int64_t kr = (int64_t)(kt + 1) * 32 + r;
+            kr = kr < a.Lk ? kr : a.Lk - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+            vs_n = tile_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, lane);
+        }
+        // S^T[key][q] = K . Q^T
+        f32x16 s = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);
+        // scale, additive mask / bias, bounds  (log2 domain)
+        float tmax = -1e30f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t key = (int64_t)kt * 32 + crow(reg, h);
+            float x = s[reg] * a.scale_log2;
+            const bool valid = key < a.Lk && !(a.causal && key > qi);
+            const int64_t kc = key < a.Lk ? key : a.Lk - 1;
+            if (mrow) x += mrow[kc] * LOG2E;
+            if (brow) x += brow[kc] * LOG2E;
+            x = valid ? x : -INFINITY;
+            s[reg] = x;
+            tmax = fmaxf(tmax, x);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mnew);
+        m = mnew;
+        float lsum = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float p = exp2f(s[reg] - m);
+            s[reg] = p;
+            lsum += p;
+        }
+        l = l * alpha + lsum;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { o0[reg] *= alpha; o1[reg] *= alpha; }
+        const s16x8 pb0 = pack_acc(s, 0), pb1 = pack_acc(s, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's V tile is in LDS
+        // O^T[d][q] += V^T[d][key] . P^T[key][q]
+        o0 = mfma32(tr_frag(tile, 0, 0, lane), pb0, o0);
+        o1 = mfma32(tr_frag(tile, 1, 0, lane), pb0, o1);
+        o0 = mfma32(tr_frag(tile, 0, 1, lane), pb1, o0);
+        o1 = mfma32(tr_frag(tile, 1, 1, lane), pb1, o1);
+    }
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    if (qi < a.Lq) {
+        store_rows(a.o + b * a.o_sb + qi * a.o_sl + head * 64, o0, o1, 1.0f / ltot, h);
+        if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi] = m + log2f(ltot);
+    }
+}
+
+// delta[b][h][q] = sum_d dO . O
+__global__ void attn_delta_kernel(AttnArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = a.B * a.Lq * a.H;
+    if (idx >= total) return;
+    const int head = (int)(idx % a.H);
+    const int64_t q = (idx / a.H) % a.Lq, b = idx / (a.H * a.Lq);
+    const bf16_t* op = a.o + b * a.o_sb + q * a.o_sl + head * 64;
+    const bf16_t* dp = a.d_o + b * a.o_sb + q * a.o_sl + head * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const s16x8 x = *(const s16x8*)(op + 8 * c), y = *(const s16x8*)(dp + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)x[j]) * bf2f((bf16_t)y[j]);
+    }
+    a.delta[(b * a.H + head) * a.lse_stride + q] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: dQ   (wave = 32 queries, streams key tiles)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t q0 = qt * 32;
+    if (q0 >= a.Lq) return;
+    char* tile = lds + wave * TILE_LDS;
+
+    const int64_t qi = q0 + r;
+    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
+    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+    const bf16_t* dop = a.d_o + b * a.o_sb + qrow * a.o_sl + head * 64;
+    s16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(qp, ks, h); dof[ks] = row_frag(dop, ks, h); }
+    const float lse = a.lse[(b * a.H + head) * a.lse_stride + qrow];
+    const float dlt = a.delta[(b * a.H + head) * a.lse_stride + qrow];
+
+    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
+    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
+    const float* mrow = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
+    const float* brow = a.pos_bias ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+    float* dbrow = a.d_pos_bias ? a.d_pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+
+    f32x16 g0 = zero16(), g1 = zero16();
+    const int nkt = (int)((a.Lk + 31) / 32);
+    for (int kt = 0; kt < nkt; ++kt) {
+        int64_t kr = (int64_t)kt * 32 + r;
+        kr = kr < a.Lk ? kr : a.Lk - 1;
+        s16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+            vf[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
+        }
+        const Stage4 kst = tile_load(kbase, a.k_sl, (int64_t)kt * 32, a.Lk, lane);
+        asm volatile("" ::: "memory");
+        tile_store(tile, kst, lane);
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t key = (int64_t)kt * 32 + crow(reg, h);
+            const bool valid = key < a.Lk && !(a.causal && key > qi);
+            const int64_t kc = key < a.Lk ? key : a.Lk - 1;
+            float x = s[reg] * a.scale_log2;
+            if (mrow) x += mrow[kc] * LOG2E;
+            if (brow) x += brow[kc] * LOG2E;
+            const float p = valid ? exp2f(x - lse) : 0.f;
+            const float ds = p * (dp[reg] - dlt);
+            if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + kc, ds);
+            s[reg] = ds;
+        }
+        const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+        g0 = mfma32(tr_frag(tile, 0, 0, lane), d0, g0);
+        g1 = mfma32(tr_frag(tile, 1, 0, lane), d0, g1);
+        g0 = mfma32(tr_frag(tile, 0, 1, lane), d1, g0);
+        g1 = mfma32(tr_frag(tile, 1, 1, lane), d1, g1);
+    }
+    if (qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: dK, dV   (wave = 32 keys, streams query tiles)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * TILE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t kt = (int64_t)blockIdx.x * 4 + wave;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t k0 = kt * 32;
+    if (k0 >= a.Lk) return;
+    char* qtile = lds + wave * 2 * TILE_LDS;
+    char* dotile = qtile + TILE_LDS;
+
+    const int64_t ki = k0 + r;
+    const int64_t krow = ki < a.Lk ? ki : a.Lk - 1;
+    const bf16_t* kp = a.k + b * a.k_sb + krow * a.k_sl + head * 64;
+    const bf16_t* vp = a.v + b * a.v_sb + krow * a.v_sl + head * 64;
+    s16x8 kfb[4], vfb[4];  // B operands: K^T[d][key], V^T[d][key]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kfb[ks] = row_frag(kp, ks, h); vfb[ks] = row_frag(vp, ks, h); }
+    const float mk = a.key_mask ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
+
+    const bf16_t* qbase = a.q + b * a.q_sb + head * 64;
+    const bf16_t* dobase = a.d_o + b * a.o_sb + head * 64;
+    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;
+    const float* drow = a.delta + (b * a.H + head) * a.lse_stride;
+    const float* bcol = a.pos_bias ? a.pos_bias + (int64_t)head * a.Lq * a.Lk + krow : nullptr;
+
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    const int nqt = (int)((a.Lq + 31) / 32);
+    for (int qt = 0; qt < nqt; ++qt) {
+        int64_t qr = (int64_t)qt * 32 + r;
+        qr = qr < a.Lq ? qr : a.Lq - 1;
+        s16x8 qfa[4], dofa[4];  // A operands: Q[q][d], dO[q][d]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qfa[ks] = row_frag(qbase + qr * a.q_sl, ks, h);
+            dofa[ks] = row_frag(dobase + qr * a.o_sl, ks, h);
+        }
+        const Stage4 qs = tile_load(qbase, a.q_sl, (int64_t)qt * 32, a.Lq, lane);
+        const Stage4 dos = tile_load(dobase, a.o_sl, (int64_t)qt * 32, a.Lq, lane);
+        asm volatile("" ::: "memory");
+        tile_store(qtile, qs, lane);
+        tile_store(dotile, dos, lane);
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S[q][key]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP[q][key] = dO . V^T
+        f32x16 p;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
+            const int64_t qc = qq < a.Lq ? qq : a.Lq - 1;
+            const bool valid = qq < a.Lq && ki < a.Lk && !(a.causal && ki > qq);
+            float x = s[reg] * a.scale_log2 + mk;
+            if (bcol) x += bcol[qc * a.Lk] * LOG2E;
+            const float pv = valid ? exp2f(x - lrow[qc]) : 0.f;
+            p[reg] = pv;
+            s[reg] = pv * (dp[reg] - drow[qc]);
+        }
+        const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
+        const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+        dv0 = mfma32(tr_frag(dotile, 0, 0, lane), p0, dv0);
+        dv1 = mfma32(tr_frag(dotile, 1, 0, lane), p0, dv1);
+        dv0 = mfma32(tr_frag(dotile, 0, 1, lane), p1, dv0);
+        dv1 = mfma32(tr_frag(dotile, 1, 1, lane), p1, dv1);
+        dk0 = mfma32(tr_frag(qtile, 0, 0, lane), d0, dk0);
+        dk1 = mfma32(tr_frag(qtile, 1, 0, lane), d0, dk1);
+        dk0 = mfma32(tr_frag(qtile, 0, 1, lane), d1, dk0);
+        dk1 = mfma32(tr_frag(qtile, 1, 1, lane), d1, dk1);
+    }
+    if (ki < a.Lk) {
+        store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
+        store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 reference-shaped path: row softmax kernels over the materialised score matrix
+// ---------------------------------------------------------------------------------------------------------
+// S[b][h][q][:] <- softmax(S + key_mask[b][:] + pos_bias[h][q][:])   (S already scaled by the GEMM's alpha)
+__global__ void softmax_rows_kernel(float* S, const float* key_mask, const float* pos_bias, int64_t B, int64_t H,
+                                    int64_t Lq, int64_t Lk, int causal) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B * H * Lq) return;
+    const int64_t q = row % Lq, hh = (row / Lq) % H, b = row / (Lq * H);
+    float* s = S + row * Lk;
+    const float* mk = key_mask ? key_mask + b * Lk : nullptr;
+    const float* pb = pos_bias ? pos_bias + (hh * Lq + q) * Lk : nullptr;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < Lk; j += 64) {
+        float x = s[j];
+        if (mk) x += mk[j];
+        if (pb) x += pb[j];
+        if (causal && j > q) x = -INFINITY;
+        s[j] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int64_t j = lane; j < Lk; j += 64) {
+        const float e = expf(s[j] - mx);
+        s[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int64_t j = lane; j < Lk; j += 64) s[j] *= inv;
+}
+
+// dS <- P * (dP - sum_j P dP)   (in place on dP)
+__global__ void softmax_bwd_rows_kernel(const float* P, float* dP, int64_t rows, int64_t Lk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = P + row * Lk;
+    float* d = dP + row * Lk;
+    float dot = 0.f;
+    for (int64_t j = lane; j < Lk; j += 64) dot += p[j] * d[j];
+    dot = wave_sum(dot);
+    for (int64_t j = lane; j < Lk; j += 64) d[j] = p[j] * (d[j] - dot);
+}
+
+// d_pos_bias[h][q][k] += sum_b dS[b][h][q][k]
+__global__ void pos_bias_grad_kernel(const float* dS, float* dpb, int64_t B, int64_t HQK) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HQK) return;
+    float acc = 0.f;
+    for (int64_t b = 0; b < B; ++b) acc += dS[b * HQK + i];
+    dpb[i] += acc;
+}
+
+m3ae_gemm_desc bgemm(const m3ae_attn_desc& d) {
+    m3ae_gemm_desc g{};
+    g.batch1 = d.B; g.batch2 = d.H;
+    g.dtype_a = g.dtype_b = g.dtype_c = M3AE_F32;
+    g.alpha = 1.0f;
+    return g;
+}
+
+int attn_f32_scores(const m3ae_attn_desc& d, float* S, hipStream_t s) {
+    const int64_t QK = d.Lq * d.Lk;
+    m3ae_gemm_desc g = bgemm(d);
+    g.M = d.Lq; g.N = d.Lk; g.K = d.Dh; g.alpha = d.scale;
+    g.A = d.q; g.a_sm = d.q_sl; g.a_sk = 1; g.a_sb1 = d.q_sb; g.a_sb2 = d.Dh;
+    g.B = d.k; g.b_sk = 1; g.b_sn = d.k_sl; g.b_sb1 = d.k_sb; g.b_sb2 = d.Dh;
+    g.C = S; g.c_sm = d.Lk; g.c_sn = 1; g.c_sb1 = d.H * QK; g.c_sb2 = QK;
+    int rc = m3ae_gemm_generic(g, s);
+    if (rc) return rc;
+    const int64_t rows = d.B * d.H * d.Lq;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, S, d.key_mask, d.pos_bias,
+                       d.B, d.H, d.Lq, d.Lk, d.causal);
+    return hip_launch_status();
+}
+
+AttnArgs to_args(const m3ae_attn_desc& d) {
+    AttnArgs a{};
+    a.q = (const bf16_t*)d.q; a.q_sb = d.q_sb; a.q_sl = d.q_sl;
+    a.k = (const bf16_t*)d.k; a.k_sb = d.k_sb; a.k_sl = d.k_sl;
+    a.v = (const bf16_t*)d.v; a.v_sb = d.v_sb; a.v_sl = d.v_sl;
+    a.o = (bf16_t*)d.o; a.o_sb = d.o_sb; a.o_sl = d.o_sl;
+    a.key_mask = d.key_mask; a.pos_bias = d.pos_bias;
+    a.scale = d.scale; a.scale_log2 = d.scale * LOG2E; a.causal = d.causal;
+    a.lse = d.lse; a.lse_stride = d.lse_stride;
+    a.B = d.B; a.H = d.H; a.Lq = d.Lq; a.Lk = d.Lk;
+    a.d_o = (const bf16_t*)d.d_o; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
+    a.delta = d.delta; a.d_pos_bias = d.d_pos_bias;
+    return a;
+}
+
+bool bf16_layout_ok(const m3ae_attn_desc& d, bool bwd) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    auto st = [](int64_t x) { return x % 8 == 0; };
+    bool ok = d.Dh == 64 && al(d.q) && al(d.k) && al(d.v) && al(d.o) && st(d.q_sl) && st(d.k_sl) && st(d.v_sl) &&
+              st(d.o_sl) && st(d.q_sb) && st(d.k_sb) && st(d.v_sb) && st(d.o_sb) && d.lse && d.lse_stride >= d.Lq &&
+              d.lse_stride % 32 == 0;
+    if (bwd) ok = ok && al(d.d_o) && al(d.dq) && al(d.dk) && al(d.dv) && d.delta;
+    return ok;
+}
+
+}  // namespace
+
+extern "C" int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward) {
+    if (!d) return 0;
+    if (d->dtype == M3AE_BF16) return 0;
+    const int64_t one = d->B * d->H * d->Lq * d->Lk * (int64_t)sizeof(float);
+    return backward ? 2 * one : one;
+}
+
+extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
+    if (!dp || !dp->q || !dp->k || !dp->v || !dp->o) return M3AE_ERR_ARG;
+    const m3ae_attn_desc& d = *dp;
+    if (d.B <= 0 || d.H <= 0 || d.Lq <= 0 || d.Lk <= 0 || d.Dh <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d.dtype == M3AE_BF16) {
+        if (!bf16_layout_ok(d, false)) return M3AE_ERR_UNSUPPORTED;
+        if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
+        AttnArgs a = to_args(d);
+        dim3 grid((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, s, a);
+        return hip_launch_status();
+    }
+    if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;
+    if (!d.workspace || d.workspace_bytes < m3ae_attn_workspace_bytes(dp, 0)) return M3AE_ERR_WORKSPACE;
+    float* S = (float*)d.workspace;
+    int rc = attn_f32_scores(d, S, s);
+    if (rc) return rc;
+    const int64_t QK = d.Lq * d.Lk;
+    m3ae_gemm_desc g = bgemm(d);
+    g.M = d.Lq; g.N = d.Dh; g.K = d.Lk;
+    g.A = S; g.a_sm = d.Lk; g.a_sk = 1; g.a_sb1 = d.H * QK; g.a_sb2 = QK;
+    g.B = d.v; g.b_sk = d.v_sl; g.b_sn = 1; g.b_sb1 = d.v_sb; g.b_sb2 = d.Dh;
+    g.C = d.o; g.c_sm = d.o_sl; g.c_sn = 1; g.c_sb1 = d.o_sb; g.c_sb2 = d.Dh;
+    return m3ae_gemm_generic(g, s);
+}
+
+extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
+    if (!dp || !dp->q || !dp->k || !dp->v || !dp->o || !dp->d_o || !dp->dq || !dp->dk || !dp->dv)
+        return M3AE_ERR_ARG;
+    const m3ae_attn_desc& d = *dp;
+    hipStream_t s = (hipStream_t)stream;
+    if (d.dtype == M3AE_BF16) {
+        if (!bf16_layout_ok(d, true)) return M3AE_ERR_UNSUPPORTED;
+        AttnArgs a = to_args(d);
+        const int64_t total = d.B * d.Lq * d.H;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
+        dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, gq, dim3(256), 0, s, a);
+        dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel, gk, dim3(256), 0, s, a);
+        return hip_launch_status();
+    }
+    if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;
+    if (!d.workspace || d.workspace_bytes < m3ae_attn_workspace_bytes(dp, 1)) return M3AE_ERR_WORKSPACE;
+    const int64_t QK = d.Lq * d.Lk;
+    float* P = (float*)d.workspace;
+    float* dS = P + d.B * d.H * QK;
+    int rc = attn_f32_scores(d, P, s);
+    if (rc) return rc;
+    // dP = dO . V^T
+    m3ae_gemm_desc g = bgemm(d);
+    g.M = d.Lq; g.N = d.Lk; g.K = d.Dh;
+    g.A = d.d_o; g.a_sm = d.o_sl; g.a_sk = 1; g.a_sb1 = d.o_sb; g.a_sb2 = d.Dh;
+    g.B = d.v; g.b_sk = 1; g.b_sn = d.v_sl; g.b_sb1 = d.v_sb; g.b_sb2 = d.Dh;
+    g.C = dS; g.c_sm = d.Lk; g.c_sn = 1; g.c_sb1 = d.H * QK; g.c_sb2 = QK;
+    if ((rc = m3ae_gemm_generic(g, s))) return rc;
+    // dV = P^T . dO   (before dS overwrites nothing of P)
+    g = bgemm(d);
+    g.M = d.Lk; g.N = d.Dh; g.K = d.Lq;
+    g.A = P; g.a_sm = 1; g.a_sk = d.Lk; g.a_sb1 = d.H * QK; g.a_sb2 = QK;
+    g.B = d.d_o; g.b_sk = d.o_sl; g.b_sn = 1; g.b_sb1 = d.o_sb; g.b_sb2 = d.Dh;
+    g.C = d.dv; g.c_sm = d.v_sl; g.c_sn = 1; g.c_sb1 = d.v_sb; g.c_sb2 = d.Dh;
+    if ((rc = m3ae_gemm_generic(g, s))) return rc;
+    const int64_t rows = d.B * d.H * d.Lq;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, P, dS, rows, d.Lk);
+    if (d.d_pos_bias) {
+        const int64_t HQK = d.H * QK;
+        hipLaunchKernelGGL(pos_bias_grad_kernel, dim3((unsigned)cdiv(HQK, 256)), dim3(256), 0, s, dS, d.d_pos_bias,
+                           d.B, HQK);
+    }
+    // dQ = scale * dS . K
+    g = bgemm(d);
+    g.M = d.Lq; g.N = d.Dh; g.K = d.Lk; g.alpha = d.scale;
+    g.A = dS; g.a_sm = d.Lk; g.a_sk = 1; g.a_sb1 = d.H * QK; g.a_sb2 = QK;
+    g.B = d.k; g.b_sk = d.k_sl; g.b_sn = 1; g.b_sb1 = d.k_sb; g.b_sb2 = d.Dh;
+    g.C = d.dq; g.c_sm = d.q_sl; g.c_sn = 1; g.c_sb1 = d.q_sb; g.c_sb2 = d.Dh;
+    if ((rc = m3ae_gemm_generic(g, s))) return rc;
+    // dK = scale * dS^T . Q
+    g = bgemm(d);
+    g.M = d.Lk; g.N = d.Dh; g.K = d.Lq; g.alpha = d.scale;
+    g.A = dS; g.a_sm = 1; g.a_sk = d.Lk; g.a_sb1 = d.H * QK; g.a_sb2 = QK;
+    g.B = d.q; g.b_sk = d.q_sl; g.b_sn = 1; g.b_sb1 = d.q_sb; g.b_sb2 = d.Dh;
+    g.C = d.dk; g.c_sm = d.k_sl; g.c_sn = 1; g.c_sb1 = d.k_sb; g.c_sb2 = d.Dh;
+    if ((rc = m3ae_gemm_generic(g, s))) return rc;
+    return hip_launch_status();
+}

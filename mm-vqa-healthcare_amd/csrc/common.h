@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 kernels of libm3ae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "m3ae_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; the plain __bf16 cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+DEVINL bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static DEVINL float ld(const float* p) { return *p; }
+    static DEVINL void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static DEVINL float ld(const bf16_t* p) { return bf2f(*p); }
+    static DEVINL void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+DEVINL float act_fwd(float x, int act) {
+    switch (act) {
+        case M3AE_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case M3AE_ACT_QUICKGELU: return x / (1.0f + expf(-1.702f * x));
+        case M3AE_ACT_TANH: return tanhf(x);
+        case M3AE_ACT_RELU: return x > 0.f ? x : 0.f;
+        default: return x;
+    }
+}
+// derivative of act at the PRE-activation value x
+DEVINL float act_bwd(float x, int act) {
+    switch (act) {
+        case M3AE_ACT_GELU: {
+            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case M3AE_ACT_QUICKGELU: {
+            float s = 1.0f / (1.0f + expf(-1.702f * x));
+            return s * (1.0f + 1.702f * x * (1.0f - s));
+        }
+        case M3AE_ACT_TANH: {
+            float t = tanhf(x);
+            return 1.0f - t * t;
+        }
+        case M3AE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        default: return 1.0f;
+    }
+}
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int hip_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,429 @@
+// Memory-bound support kernels of the hot path: embedding gather / scatter, patch extraction, token assembly,
+// column sums, losses, the fused AdamW update and dtype / layout conversions.  All are HBM-streaming kernels:
+// coalesced 4-16 B per lane, grid-stride, fp32 arithmetic.
+#include "common.h"
+
+namespace {
+
+template <typename T> DEVINL float ldf(const void* p, int64_t i) { return Elem<T>::ld((const T*)p + i); }
+template <typename T> DEVINL void stf(void* p, int64_t i, float v) { Elem<T>::st((T*)p + i, v); }
+
+#define DT_SWITCH(dtype, CALL)                        \
+    do {                                              \
+        if ((dtype) == M3AE_F32) { using T = float; CALL; }        \
+        else if ((dtype) == M3AE_BF16) { using T = bf16_t; CALL; } \
+        else return M3AE_ERR_UNSUPPORTED;             \
+    } while (0)
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(int64_t n) {
+    int64_t g = cdiv(n, EW_BLOCK);
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// ---- column sum ------------------------------------------------------------------------------------------
+// grid (cdiv(N, 256), row_chunks); each thread owns one column for its row chunk, one fp32 atomic per column.
+template <typename T>
+__global__ void colsum_kernel(const T* x, float* out, int64_t M, int64_t N, int64_t ldx, int64_t rows_per) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+    int64_t r1 = r0 + rows_per;
+    if (r1 > M) r1 = M;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += Elem<T>::ld(x + r * ldx + n);
+    atomicAdd(out + n, acc);
+}
+
+// ---- RoBERTa embeddings ------------------------------------------------------------------------------------
+// one workgroup per sample: position ids by a serial scan over S (S <= 512), then D-wide gathers
+template <typename T>
+__global__ void roberta_embed_fwd_kernel(const int64_t* ids, const float* word, const float* pos, const float* type,
+                                         T* out, int64_t S, int64_t D, int64_t pad_id) {
+    extern __shared__ int pos_ids[];
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int64_t s = 0; s < S; ++s) {
+            const int ne = ids[b * S + s] != pad_id;
+            run += ne;
+            pos_ids[s] = run * ne + (int)pad_id;
+        }
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < S * D; i += blockDim.x) {
+        const int64_t s = i / D, d = i - s * D;
+        const int64_t id = ids[b * S + s];
+        const float v = word[id * D + d] + type[d] + pos[(int64_t)pos_ids[s] * D + d];
+        Elem<T>::st(out + (b * S + s) * D + d, v);
+    }
+}
+template <typename T>
+__global__ void roberta_embed_bwd_kernel(const int64_t* ids, const T* d_out, float* d_word, float* d_pos, int64_t S,
+                                         int64_t D, int64_t pad_id) {
+    extern __shared__ int pos_ids[];
+    const int64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int64_t s = 0; s < S; ++s) {
+            const int ne = ids[b * S + s] != pad_id;
+            run += ne;
+            pos_ids[s] = run * ne + (int)pad_id;
+        }
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < S * D; i += blockDim.x) {
+        const int64_t s = i / D, d = i - s * D;
+        const int64_t id = ids[b * S + s];
+        const float g = Elem<T>::ld(d_out + (b * S + s) * D + d);
+        atomicAdd(d_word + id * D + d, g);
+        atomicAdd(d_pos + (int64_t)pos_ids[s] * D + d, g);
+    }
+}
+
+// ---- ViT patches -----------------------------------------------------------------------------------------
+// out[(b * G + gy * g + gx)][c * P * P + py * P + px] = img[b][c][gy * P + py][gx * P + px]
+template <typename T>
+__global__ void patchify_kernel(const float* img, T* out, int64_t B, int64_t R, int64_t P) {
+    const int64_t g = R / P, K = 3 * P * P, total = B * g * g * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = i % K, tok = i / K;
+        const int64_t px = col % P, py = (col / P) % P, c = col / (P * P);
+        const int64_t gx = tok % g, gy = (tok / g) % g, b = tok / (g * g);
+        Elem<T>::st(out + i, img[((b * 3 + c) * R + gy * P + py) * R + gx * P + px]);
+    }
+}
+// out[b][0] = cls + pos[0];  out[b][1 + i] = patch[b][i] + pos[1 + i]
+template <typename T>
+__global__ void vit_tokens_fwd_kernel(const T* patch, const float* cls, const float* pos, T* out, int64_t B, int64_t G,
+                                      int64_t D) {
+    const int64_t L = G + 1, total = B * L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = i % D, l = (i / D) % L, b = i / (D * L);
+        const float base = l == 0 ? cls[d] : Elem<T>::ld(patch + (b * G + l - 1) * D + d);
+        Elem<T>::st(out + i, base + pos[l * D + d]);
+    }
+}
+// d_patch = d_out[:, 1:];  d_pos[l] += sum_b d_out[b][l];  d_cls += sum_b d_out[b][0]
+template <typename T>
+__global__ void vit_tokens_bwd_kernel(const T* d_out, T* d_patch, float* d_cls, float* d_pos, int64_t B, int64_t G,
+                                      int64_t D) {
+    const int64_t L = G + 1, total = L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = i % D, l = i / D;
+        float acc = 0.f;
+        for (int64_t b = 0; b < B; ++b) {
+            const T raw = d_out[(b * L + l) * D + d];
+            if (l > 0) d_patch[(b * G + l - 1) * D + d] = raw;
+            acc += Elem<T>::ld(&raw);
+        }
+        d_pos[i] += acc;
+        if (l == 0) d_cls[d] += acc;
+    }
+}
+
+// ---- losses -----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bce_kernel(const T* x, const float* z, float* loss, T* dx, int64_t n, float inv_n, float C,
+                           float grad_scale) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float xi = Elem<T>::ld(x + i), zi = z[i];
+        acc += fmaxf(xi, 0.f) - xi * zi + log1pf(expf(-fabsf(xi)));
+        const float sig = 1.0f / (1.0f + expf(-xi));
+        if (dx) Elem<T>::st(dx + i, (sig - zi) * inv_n * C * grad_scale);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n * C);
+}
+
+// cross entropy: ws[0] = number of rows with label != -100 ; one workgroup per row
+__global__ void xent_count_kernel(const int64_t* labels, float* ws, int64_t rows) {
+    float c = 0.f;
+    for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) c += labels[i] != -100 ? 1.f : 0.f;
+    c = wave_sum(c);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[0] = part[0] + part[1] + part[2] + part[3];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void xent_kernel(const T* x, const int64_t* labels, float* loss, T* dx, const float* ws,
+                                                   int64_t C, int64_t ld, float grad_scale) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const int64_t lab = labels[row];
+    const T* xr = x + row * ld;
+    T* dr = dx ? dx + row * ld : nullptr;
+    if (lab == -100) {
+        if (dr) for (int64_t j = threadIdx.x; j < C; j += 256) Elem<T>::st(dr + j, 0.f);
+        return;
+    }
+    float mx = -INFINITY;
+    for (int64_t j = threadIdx.x; j < C; j += 256) mx = fmaxf(mx, Elem<T>::ld(xr + j));
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int64_t j = threadIdx.x; j < C; j += 256) sum += expf(Elem<T>::ld(xr + j) - mx);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    const float inv_valid = 1.0f / ws[0];
+    const float lse = mx + logf(sum);
+    if (threadIdx.x == 0) atomicAdd(loss, (lse - Elem<T>::ld(xr + lab)) * inv_valid);
+    if (dr) {
+        const float gs = grad_scale * inv_valid;
+        for (int64_t j = threadIdx.x; j < C; j += 256) {
+            const float p = expf(Elem<T>::ld(xr + j) - lse);
+            Elem<T>::st(dr + j, (p - (j == lab ? 1.f : 0.f)) * gs);
+        }
+    }
+}
+
+// ---- AdamW (transformers 4.6.0 semantics) -----------------------------------------------------------------
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* shadow, int64_t n4, float lr,
+                             float b1, float b2, float eps, float wd, float step_size, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const f32x4 gg = ((const f32x4*)g)[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float gt = gg[t] * grad_scale;
+            mm[t] = mm[t] * b1 + gt * (1.0f - b1);
+            vv[t] = vv[t] * b2 + gt * gt * (1.0f - b2);
+            const float denom = sqrtf(vv[t]) + eps;
+            pp[t] = pp[t] - step_size * (mm[t] / denom);
+            if (wd > 0.f) pp[t] = pp[t] - lr * wd * pp[t];
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (shadow) ((u32x2*)shadow)[i] = (u32x2){pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
+    }
+}
+
+// ---- cast / transpose -------------------------------------------------------------------------------------
+__global__ void cast_transpose_kernel(const float* in, bf16_t* out, bf16_t* out_t, int64_t R, int64_t C) {
+    __shared__ float tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + j, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = in[r * C + c];
+            if (out) out[r * C + c] = f2bf(v);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    if (out_t) {
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t c = c0 + j, r = r0 + tx;
+            if (r < R && c < C) out_t[c * R + r] = f2bf(tile[tx][j]);
+        }
+    }
+}
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* in, TO* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<TO>::st(out + i, Elem<TI>::ld(in + i));
+}
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
+template <typename T>
+__global__ void act_fwd_kernel(const T* x, T* y, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(y + i, act_fwd(Elem<T>::ld(x + i), act));
+}
+template <typename T>
+__global__ void act_bwd_kernel(const T* dy, const T* x, T* dx, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(dx + i, Elem<T>::ld(dy + i) * act_bwd(Elem<T>::ld(x + i), act));
+}
+template <typename T>
+__global__ void gather_rows_kernel(const T* in, const int64_t* idx, T* out, int64_t n_out, int64_t D) {
+    const int64_t total = n_out * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D, d = i - r * D;
+        out[i] = in[idx[r] * D + d];
+    }
+}
+template <typename T>
+__global__ void scatter_add_rows_kernel(const T* d_out, const int64_t* idx, T* d_in, int64_t n_out, int64_t D) {
+    // rows of idx are distinct per destination in the MIM use (a permutation slice), so plain read-modify-write
+    const int64_t total = n_out * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D, d = i - r * D;
+        const int64_t o = idx[r] * D + d;
+        Elem<T>::st(d_in + o, Elem<T>::ld(d_in + o) + Elem<T>::ld(d_out + i));
+    }
+}
+
+}  // namespace
+
+extern "C" int m3ae_abi_version(void) { return M3AE_ABI_VERSION; }
+
+extern "C" int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
+                           void* stream) {
+    if (!x || !out || M <= 0 || N <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, N * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    int64_t chunks = cdiv(M, 256);
+    if (chunks > 256) chunks = 256;
+    const int64_t rows_per = cdiv(M, chunks);
+    chunks = cdiv(M, rows_per);
+    dim3 grid((unsigned)cdiv(N, 256), (unsigned)chunks);
+    DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, out, M, N, ldx, rows_per));
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type,
+                                      void* out, int64_t B, int64_t S, int64_t D, int64_t pad_id, int dtype,
+                                      void* stream) {
+    if (!ids || !word || !pos || !type || !out || B <= 0 || S <= 0 || S > 4096) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(roberta_embed_fwd_kernel<T>, dim3((unsigned)B), dim3(256), S * sizeof(int), s,
+                                        ids, word, pos, type, (T*)out, S, D, pad_id));
+    return hip_launch_status();
+}
+extern "C" int m3ae_roberta_embed_bwd(const int64_t* ids, const void* d_out, float* d_word, float* d_pos,
+                                      float* d_type, int64_t B, int64_t S, int64_t D, int64_t pad_id, int dtype,
+                                      void* stream) {
+    if (!ids || !d_out || !d_word || !d_pos || B <= 0 || S <= 0 || S > 4096) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(roberta_embed_bwd_kernel<T>, dim3((unsigned)B), dim3(256), S * sizeof(int), s,
+                                        ids, (const T*)d_out, d_word, d_pos, S, D, pad_id));
+    int rc = hip_launch_status();
+    if (rc) return rc;
+    if (d_type) return m3ae_colsum(d_out, d_type, B * S, D, D, dtype, 1, stream);  // token_type 0 for every token
+    return 0;
+}
+
+extern "C" int m3ae_patchify(const float* img, void* out, int64_t B, int64_t R, int64_t P, int dtype, void* stream) {
+    if (!img || !out || B <= 0 || R <= 0 || P <= 0 || R % P) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = B * (R / P) * (R / P) * 3 * P * P;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, img, (T*)out, B, R, P));
+    return hip_launch_status();
+}
+extern "C" int m3ae_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* out, int64_t B,
+                                   int64_t G, int64_t D, int dtype, void* stream) {
+    if (!patch || !cls || !pos || !out) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(vit_tokens_fwd_kernel<T>, dim3(ew_grid(B * (G + 1) * D)), dim3(EW_BLOCK), 0, s,
+                                        (const T*)patch, cls, pos, (T*)out, B, G, D));
+    return hip_launch_status();
+}
+extern "C" int m3ae_vit_tokens_bwd(const void* d_out, void* d_patch, float* d_cls, float* d_pos, int64_t B, int64_t G,
+                                   int64_t D, int dtype, void* stream) {
+    if (!d_out || !d_patch || !d_cls || !d_pos) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(vit_tokens_bwd_kernel<T>, dim3(ew_grid((G + 1) * D)), dim3(EW_BLOCK), 0, s,
+                                        (const T*)d_out, (T*)d_patch, d_cls, d_pos, B, G, D));
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_bce_logits(const void* logits, const float* targets, float* loss, void* d_logits, int64_t B,
+                               int64_t C, float grad_scale, int dtype, void* stream) {
+    if (!logits || !targets || !loss || B <= 0 || C <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t n = B * C;
+    unsigned grid = ew_grid(n);
+    if (grid > 64) grid = 64;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(bce_kernel<T>, dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)logits, targets, loss,
+                                        (T*)d_logits, n, 1.0f / (float)n, (float)C, grad_scale));
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_xent(const void* logits, const int64_t* labels, float* loss, void* d_logits, float* workspace,
+                         int64_t rows, int64_t C, int64_t ld, float grad_scale, int dtype, void* stream) {
+    if (!logits || !labels || !loss || !workspace || rows <= 0 || C <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(xent_count_kernel, dim3(1), dim3(256), 0, s, labels, workspace, rows);
+    DT_SWITCH(dtype, hipLaunchKernelGGL(xent_kernel<T>, dim3((unsigned)rows), dim3(256), 0, s, (const T*)logits, labels,
+                                        loss, (T*)d_logits, workspace, C, ld, grad_scale));
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float wd, int64_t step, float grad_scale,
+                          void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return M3AE_ERR_ARG;
+    if (n % 4 != 0 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return M3AE_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4)), dim3(EW_BLOCK), 0, s, p, g, m, v, (bf16_t*)shadow_bf16, n / 4,
+                       lr, beta1, beta2, eps, wd, step_size, grad_scale);
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_cast_transpose(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream) {
+    if (!in || R <= 0 || C <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
+    if (grid.y > 65535u) return M3AE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, s, in, (bf16_t*)out, (bf16_t*)out_t, R, C);
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream) {
+    if (!in || !out || n <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(ew_grid(n)), b(EW_BLOCK);
+    if (dtype_in == M3AE_F32 && dtype_out == M3AE_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, n);
+    else if (dtype_in == M3AE_BF16 && dtype_out == M3AE_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, n);
+    else if (dtype_in == M3AE_F32 && dtype_out == M3AE_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, n);
+    else if (dtype_in == M3AE_BF16 && dtype_out == M3AE_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, n);
+    else return M3AE_ERR_UNSUPPORTED;
+    return hip_launch_status();
+}
+extern "C" int m3ae_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)a, (const T*)b, (T*)out, n));
+    return hip_launch_status();
+}
+extern "C" int m3ae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream) {
+    if (!x || !y || n <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(act_fwd_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)x, (T*)y, n, act));
+    return hip_launch_status();
+}
+extern "C" int m3ae_act_bwd(const void* dy, const void* x_pre, void* dx, int64_t n, int act, int dtype, void* stream) {
+    if (!dy || !x_pre || !dx || n <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)dy, (const T*)x_pre, (T*)dx, n, act));
+    return hip_launch_status();
+}
+extern "C" int m3ae_gather_rows(const void* in, const int64_t* idx, void* out, int64_t n_out, int64_t D, int dtype,
+                                void* stream) {
+    if (!in || !idx || !out || n_out <= 0 || D <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(ew_grid(n_out * D)), dim3(EW_BLOCK), 0, s, (const T*)in, idx, (T*)out, n_out, D));
+    return hip_launch_status();
+}
+extern "C" int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void* d_in, int64_t n_out, int64_t D,
+                                     int dtype, void* stream) {
+    if (!d_out || !idx || !d_in || n_out <= 0 || D <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(scatter_add_rows_kernel<T>, dim3(ew_grid(n_out * D)), dim3(EW_BLOCK), 0, s, (const T*)d_out, idx, (T*)d_in, n_out, D));
+    return hip_launch_status();
+}

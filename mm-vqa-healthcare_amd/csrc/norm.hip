@@ -1,0 +1,242 @@
+// LayerNorm / RMSNorm forward + backward (HBM-bound: one pass over x, fp32 statistics, wave64 reductions).
+//
+// One wave per row; the row lives in registers (4-element chunks, CPL chunks per lane) so x is read once.
+// Statistics are two-pass in registers (mean, then variance of the centred values), matching nn.LayerNorm's
+// fp32 numerics (clip_model.py:27-33 upcasts to fp32; bert_model.py:357 eps 1e-12 needs the centred form).
+// Backward keeps per-lane partial dgamma/dbeta over the rows a wave walks, combines the 4 waves of a workgroup in
+// LDS, writes one partial row per workgroup, and a second kernel folds the partials into the fp32 gradients.
+#include "common.h"
+
+namespace {
+
+template <typename T> DEVINL void ld4(const T* p, float* x);
+template <> DEVINL void ld4<float>(const float* p, float* x) {
+    const f32x4 v = *(const f32x4*)p;
+    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+}
+template <> DEVINL void ld4<bf16_t>(const bf16_t* p, float* x) {
+    const u32x2 v = *(const u32x2*)p;
+    x[0] = __uint_as_float(v[0] << 16); x[1] = __uint_as_float(v[0] & 0xffff0000u);
+    x[2] = __uint_as_float(v[1] << 16); x[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+template <typename T> DEVINL void st4(T* p, const float* x);
+template <> DEVINL void st4<float>(float* p, const float* x) { *(f32x4*)p = (f32x4){x[0], x[1], x[2], x[3]}; }
+template <> DEVINL void st4<bf16_t>(bf16_t* p, const float* x) {
+    *(u32x2*)p = (u32x2){pack2bf(x[0], x[1]), pack2bf(x[2], x[3])};
+}
+
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                     float* mean_o, float* rstd_o, int64_t M, int D, float eps,
+                                                     int act, int rms) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = D >> 2;
+    const T* xr = x + row * D;
+    float v[CPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            ld4<T>(xr + ch * 4, v[c]);
+            sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        } else {
+            v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        }
+    }
+    const float mean = rms ? 0.f : wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float dlt = v[c][t] - mean;
+                sq += dlt * dlt;
+            }
+        }
+    }
+    const float var = wave_sum(sq) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+    }
+    T* yr = y + row * D;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+            float g[4], b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+            ld4<float>(gamma + ch * 4, g);
+            if (beta) ld4<float>(beta + ch * 4, b);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = act_fwd((v[c][t] - mean) * rstd * g[t] + b[t], act);
+            st4<T>(yr + ch * 4, o);
+        }
+    }
+}
+
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* beta,
+                                                     const float* mean_i, const float* rstd_i, T* dx, float* part,
+                                                     int64_t M, int D, int act, int rms) {
+    extern __shared__ float red[];  // [4 waves][2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    float dg[CPL][4], db[CPL][4], g[CPL][4], bt[CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + c * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { dg[c][t] = 0.f; db[c][t] = 0.f; g[c][t] = 0.f; bt[c][t] = 0.f; }
+        if (ch < nch) {
+            ld4<float>(gamma + ch * 4, g[c]);
+            if (beta) ld4<float>(beta + ch * 4, bt[c]);
+        }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mean = rms ? 0.f : mean_i[row];
+        const float rstd = rstd_i[row];
+        float xh[CPL][4], dxh[CPL][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                float xv[4], dv[4];
+                ld4<T>(x + row * D + ch * 4, xv);
+                ld4<T>(dy + row * D + ch * 4, dv);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float h = (xv[t] - mean) * rstd;
+                    float d = dv[t];
+                    if (act != M3AE_ACT_NONE) d *= act_bwd(h * g[c][t] + bt[c][t], act);
+                    dg[c][t] += d * h;
+                    db[c][t] += d;
+                    const float dh = d * g[c][t];
+                    xh[c][t] = h;
+                    dxh[c][t] = dh;
+                    s1 += dh;
+                    s2 += dh * h;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { xh[c][t] = 0.f; dxh[c][t] = 0.f; }
+            }
+        }
+        const float c1 = rms ? 0.f : wave_sum(s1) / (float)D;
+        const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = rstd * (dxh[c][t] - c1 - xh[c][t] * c2);
+                st4<T>(dx + row * D + ch * 4, o);
+            }
+        }
+    }
+    // combine the 4 waves, one partial row per workgroup
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                red[(wave * 2 + 0) * D + ch * 4 + t] = dg[c][t];
+                red[(wave * 2 + 1) * D + ch * 4 + t] = db[c][t];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int which = i / D, col = i - which * D;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * D + col];
+        part[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblk, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * D) return;
+    const int which = i / D, col = i - which * D;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 2 + which) * D + col];
+    if (which == 0) dgamma[col] += s;
+    else if (dbeta) dbeta[col] += s;
+}
+
+template <typename T, int CPL>
+int launch_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t M, int D,
+               float eps, int act, int rms, hipStream_t s) {
+    hipLaunchKernelGGL((ln_fwd_kernel<T, CPL>), dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y,
+                       mean, rstd, M, D, eps, act, rms);
+    return hip_launch_status();
+}
+template <typename T, int CPL>
+int launch_bwd(const void* dy, const void* x, const float* g, const float* b, const float* mean, const float* rstd,
+               void* dx, float* part, int nblk, int64_t M, int D, int act, int rms, hipStream_t s) {
+    hipLaunchKernelGGL((ln_bwd_kernel<T, CPL>), dim3((unsigned)nblk), dim3(256), (size_t)8 * D * sizeof(float), s,
+                       (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, part, M, D, act, rms);
+    return hip_launch_status();
+}
+
+#define DISPATCH_CPL(FN, T, ...)                                                  \
+    do {                                                                          \
+        const int cpl = (int)cdiv(D / 4, 64);                                     \
+        if (cpl <= 1) return FN<T, 1>(__VA_ARGS__);                               \
+        if (cpl <= 2) return FN<T, 2>(__VA_ARGS__);                               \
+        if (cpl <= 3) return FN<T, 3>(__VA_ARGS__);                               \
+        if (cpl <= 4) return FN<T, 4>(__VA_ARGS__);                               \
+        if (cpl <= 6) return FN<T, 6>(__VA_ARGS__);                               \
+        if (cpl <= 8) return FN<T, 8>(__VA_ARGS__);                               \
+        if (cpl <= 16) return FN<T, 16>(__VA_ARGS__);                             \
+        return M3AE_ERR_UNSUPPORTED;                                              \
+    } while (0)
+
+}  // namespace
+
+extern "C" int m3ae_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                  float* rstd, int64_t M, int64_t D, float eps, int dtype, int act, int rms,
+                                  void* stream) {
+    if (!x || !gamma || !y || M <= 0 || D <= 0) return M3AE_ERR_ARG;
+    if (D % 4 != 0 || D > 4096) return M3AE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == M3AE_F32) DISPATCH_CPL(launch_fwd, float, x, gamma, beta, y, mean, rstd, M, (int)D, eps, act, rms, s);
+    if (dtype == M3AE_BF16) DISPATCH_CPL(launch_fwd, bf16_t, x, gamma, beta, y, mean, rstd, M, (int)D, eps, act, rms, s);
+    return M3AE_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t m3ae_layernorm_bwd_blocks(int64_t M) {
+    int64_t n = cdiv(M, 4);
+    return n < 1024 ? n : 1024;
+}
+
+extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                  float* workspace, int64_t M, int64_t D, int dtype, int act, int rms, void* stream) {
+    if (!dy || !x || !gamma || !rstd || !dx || !dgamma || !workspace || M <= 0) return M3AE_ERR_ARG;
+    if (D % 4 != 0 || D > 4096) return M3AE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)m3ae_layernorm_bwd_blocks(M);
+    int rc = M3AE_ERR_UNSUPPORTED;
+    auto run = [&]() -> int {
+        if (dtype == M3AE_F32)
+            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, workspace, nblk, M, (int)D, act, rms, s);
+        if (dtype == M3AE_BF16)
+            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, workspace, nblk, M, (int)D, act, rms, s);
+        return M3AE_ERR_UNSUPPORTED;
+    };
+    rc = run();
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 256)), dim3(256), 0, s, workspace, dgamma,
+                       dbeta, nblk, (int)D);
+    return hip_launch_status();
+}

@@ -1,0 +1,97 @@
+"""ctypes binding of libm3ae_hip.so (include/m3ae_hip.h).  Loading fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libm3ae_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", i64), ("N", i64), ("K", i64), ("batch1", i64), ("batch2", i64),
+        ("A", vp), ("a_sm", i64), ("a_sk", i64), ("a_sb1", i64), ("a_sb2", i64),
+        ("B", vp), ("b_sk", i64), ("b_sn", i64), ("b_sb1", i64), ("b_sb2", i64),
+        ("C", vp), ("c_sm", i64), ("c_sn", i64), ("c_sb1", i64), ("c_sb2", i64),
+        ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
+        ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
+        ("dact_aux", vp), ("dact", i32), ("force_generic", i32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("B", i64), ("H", i64), ("Lq", i64), ("Lk", i64), ("Dh", i64),
+        ("q", vp), ("q_sb", i64), ("q_sl", i64),
+        ("k", vp), ("k_sb", i64), ("k_sl", i64),
+        ("v", vp), ("v_sb", i64), ("v_sl", i64),
+        ("o", vp), ("o_sb", i64), ("o_sl", i64),
+        ("key_mask", vp), ("pos_bias", vp), ("scale", f32), ("causal", i32),
+        ("lse", vp), ("lse_stride", i64), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
+        ("d_o", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp), ("d_pos_bias", vp),
+    ]
+
+
+_SIGS = {
+    "m3ae_abi_version": (C.c_int, []),
+    "m3ae_last_gemm_path": (C.c_char_p, []),
+    "m3ae_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "m3ae_attn_workspace_bytes": (i64, [C.POINTER(AttnDesc), C.c_int]),
+    "m3ae_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "m3ae_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "m3ae_layernorm_bwd_blocks": (i64, [i64]),
+    "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "m3ae_colsum": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
+    "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
+    "m3ae_patchify": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, vp]),
+    "m3ae_vit_tokens_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "m3ae_vit_tokens_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "m3ae_bce_logits": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, C.c_int, vp]),
+    "m3ae_xent": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, f32, C.c_int, vp]),
+    "m3ae_adamw": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+    "m3ae_cast_transpose": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "m3ae_cast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "m3ae_add": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "m3ae_act_fwd": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "m3ae_act_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, vp]),
+    "m3ae_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
+    "m3ae_scatter_add_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
+    "m3ae_selftest": (C.c_int, [vp, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class M3AEHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (python -m m3ae_amd.build) -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M3AEHipError(f"{LIB_PATH} is missing: build it with `python -m m3ae_amd.build` "
+                               f"(or __graft_entry__.build()); this package has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if l.m3ae_abi_version() != 1:
+            raise M3AEHipError("ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape/dtype", -3: "misaligned", -4: "workspace too small"}.get(
+            rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise M3AEHipError(f"{what} failed: {kind}")

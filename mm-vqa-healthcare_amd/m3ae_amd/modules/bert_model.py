@@ -1,0 +1,186 @@
+"""BertCrossLayer / BertSelfLayer on the MI355X kernels -- same module tree and parameter names as the reference's
+m3ae/modules/language_encoders/bert_model.py:211-546 (and HF RobertaLayer, whose math and names are identical).
+
+Each block is three fused pieces instead of the reference's ~20 ATen calls:
+  packed Q|K|V (or Q and K|V) projection GEMM -> flash attention -> output GEMM with the residual add in its
+  epilogue -> LayerNorm;   FFN = GEMM(+bias+erf-GELU, pre-activation kept) -> GEMM(+bias+residual) -> LayerNorm.
+Attention probabilities are never materialised (the reference hard-wires output_attentions=True,
+m3ae_module.py:276-277).  Dropout: see DESIGN.md (parity runs are eval-mode).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..param_store import PackedParam
+
+
+class BertSelfAttention(nn.Module):
+    """bert_model.py:211-350.  `query/key/value` stay separate nn.Linear parameters (state_dict names); the
+    kernels read them as one packed projection through PackedParam views of the flat parameter buffer."""
+
+    def __init__(self, hidden, heads):
+        super().__init__()
+        self.num_attention_heads = heads
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(hidden, hidden)
+        self.value = nn.Linear(hidden, hidden)
+        self._packs = {}
+
+    def pack(self, kind):
+        if kind not in self._packs:
+            mods = {"qkv": (self.query, self.key, self.value), "kv": (self.key, self.value)}[kind]
+            self._packs[kind] = (PackedParam([m.weight for m in mods]), PackedParam([m.bias for m in mods]))
+        return self._packs[kind]
+
+    def weight_units(self, cross):
+        if cross:
+            return [self.query.weight, self.pack("kv")[0]]
+        return [self.pack("qkv")[0]]
+
+
+class BertSelfOutput(nn.Module):
+    """bert_model.py:353-364."""
+
+    def __init__(self, hidden, eps):
+        super().__init__()
+        self.dense = nn.Linear(hidden, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class BertAttention(nn.Module):
+    """bert_model.py:367-413: self- or cross-attention + output dense + residual + LayerNorm."""
+
+    def __init__(self, hidden, heads, eps, cross=False):
+        super().__init__()
+        self.self = BertSelfAttention(hidden, heads)
+        self.output = BertSelfOutput(hidden, eps)
+        self.cross = cross
+
+    def forward(self, h, key_mask=None, other=None, other_mask=None):
+        heads = self.self.num_attention_heads
+        if other is None:
+            w, b = self.self.pack("qkv")
+            qkv = ops.linear(h, w, b)
+            ctx = ops.self_attention(qkv, key_mask, heads)
+        else:
+            q = ops.linear(h, self.self.query.weight, self.self.query.bias)
+            w, b = self.self.pack("kv")
+            kv = ops.linear(other, w, b)
+            ctx = ops.cross_attention(q, kv, other_mask, heads)
+        s = ops.linear(ctx, self.output.dense.weight, self.output.dense.bias, residual=h)
+        ln = self.output.LayerNorm
+        return ops.layer_norm(s, ln.weight, ln.bias, ln.eps)
+
+    def weight_units(self):
+        return self.self.weight_units(self.cross) + [self.output.dense.weight]
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, hidden, inter):
+        super().__init__()
+        self.dense = nn.Linear(hidden, inter)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, hidden, inter, eps):
+        super().__init__()
+        self.dense = nn.Linear(inter, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+
+
+def _ffn(layer, h):
+    """feed_forward_chunk (bert_model.py:500-503)."""
+    s = ops.mlp(h, layer.intermediate.dense.weight, layer.intermediate.dense.bias, layer.output.dense.weight,
+                layer.output.dense.bias, ops.ACT_GELU, residual=h)
+    ln = layer.output.LayerNorm
+    return ops.layer_norm(s, ln.weight, ln.bias, ln.eps)
+
+
+class BertCrossLayer(nn.Module):
+    """bert_model.py:445-503: self-attention -> cross-attention (residual = self-attention output) -> FFN."""
+
+    def __init__(self, hidden, heads, inter, eps=1e-12):
+        super().__init__()
+        self.attention = BertAttention(hidden, heads, eps)
+        self.crossattention = BertAttention(hidden, heads, eps, cross=True)
+        self.intermediate = BertIntermediate(hidden, inter)
+        self.output = BertOutput(hidden, inter, eps)
+
+    def forward(self, hidden_states, encoder_hidden_states, attention_mask=None, encoder_attention_mask=None):
+        a = self.attention(hidden_states, attention_mask)
+        c = self.crossattention(a, None, encoder_hidden_states, encoder_attention_mask)
+        return _ffn(self, c)
+
+    def weight_units(self):
+        return (self.attention.weight_units() + self.crossattention.weight_units()
+                + [self.intermediate.dense.weight, self.output.dense.weight])
+
+
+class BertSelfLayer(nn.Module):
+    """bert_model.py:506-546 == HF RobertaLayer (called at m3ae_module.py:233-234)."""
+
+    def __init__(self, hidden, heads, inter, eps=1e-5):
+        super().__init__()
+        self.attention = BertAttention(hidden, heads, eps)
+        self.intermediate = BertIntermediate(hidden, inter)
+        self.output = BertOutput(hidden, inter, eps)
+
+    def forward(self, hidden_states, attention_mask=None):
+        return _ffn(self, self.attention(hidden_states, attention_mask))
+
+    def weight_units(self):
+        return self.attention.weight_units() + [self.intermediate.dense.weight, self.output.dense.weight]
+
+
+class RobertaEmbeddings(nn.Module):
+    """HF RobertaEmbeddings (third party; m3ae_module.py:230)."""
+
+    def __init__(self, vocab, hidden, max_pos, type_vocab=1, pad_id=1, eps=1e-5):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, hidden, padding_idx=pad_id)
+        self.position_embeddings = nn.Embedding(max_pos, hidden, padding_idx=pad_id)
+        self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+        self.padding_idx = pad_id
+
+    def forward(self, input_ids, dtype):
+        e = ops.roberta_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                              self.token_type_embeddings.weight, self.padding_idx, dtype)
+        return ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class RobertaEncoder(nn.Module):
+    def __init__(self, layers, hidden, heads, inter):
+        super().__init__()
+        self.layer = nn.ModuleList([BertSelfLayer(hidden, heads, inter, eps=1e-5) for _ in range(layers)])
+
+
+class RobertaPooler(nn.Module):
+    """Present in the reference's state_dict, never used by infer."""
+
+    def __init__(self, hidden):
+        super().__init__()
+        self.dense = nn.Linear(hidden, hidden)
+
+
+class RobertaModel(nn.Module):
+    """Parameter-name-compatible stand-in for transformers' RobertaModel as the reference uses it
+    (m3ae_module.py:66,230-234): embeddings + encoder.layer[*]; `pooler` kept for key compatibility."""
+
+    def __init__(self, vocab, hidden, layers, heads, inter, max_pos=514):
+        super().__init__()
+        self.embeddings = RobertaEmbeddings(vocab, hidden, max_pos)
+        self.encoder = RobertaEncoder(layers, hidden, heads, inter)
+        self.pooler = RobertaPooler(hidden)
+
+    @staticmethod
+    def get_extended_attention_mask(mask):
+        """transformers-4.6.0 semantics (m3ae_module.py:232): (1 - mask) * -10000.0, here kept as [B, L] fp32 --
+        the kernels broadcast it over heads and queries."""
+        return (1.0 - mask.to(torch.float32)) * -10000.0
+
+    def weight_units(self):
+        u = []
+        for l in self.encoder.layer:
+            u += l.weight_units()
+        return u

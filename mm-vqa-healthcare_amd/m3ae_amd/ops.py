@@ -1,0 +1,615 @@
+"""Autograd operators of the hot path, each a thin host wrapper over the C ABI (include/m3ae_hip.h).
+
+PyTorch supplies device memory, the stream and the autograd tape; every FLOP on the path runs in libm3ae_hip.so.
+Parameter gradients are ACCUMULATED IN PLACE into `param.grad` (fp32, normally a view of ParamStore's flat
+gradient buffer) by the wgrad / reduction kernels themselves, and the Functions return None for them: no autograd
+accumulation kernels, and the data-parallel reducer (m3ae_amd/ddp.py) is told the moment a gradient is complete
+through `grad_ready_hook`.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, check)
+
+grad_ready_hook = None  # callable(param) set by the DDP reducer
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise _lib.M3AEHipError("m3ae_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+def compute_weight(w):
+    """The tensor a GEMM reads for parameter `w`: its bf16 shadow in perf mode, itself in fp32 mode."""
+    return getattr(w, "m3ae_c", w)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# raw GEMM
+# ----------------------------------------------------------------------------------------------------------
+def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulate=False, bias=None, act=ACT_NONE,
+         preact=None, residual=None, dact_aux=None, dact=ACT_NONE, force_generic=False, batch=(1, 1),
+         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0)):
+    _need_cuda(c)
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch1, d.batch2 = batch
+    d.A, d.a_sm, d.a_sk, d.a_sb1, d.a_sb2 = a.data_ptr(), a_sm, a_sk, a_sb[0], a_sb[1]
+    d.B, d.b_sk, d.b_sn, d.b_sb1, d.b_sb2 = b.data_ptr(), b_sk, b_sn, b_sb[0], b_sb[1]
+    d.C, d.c_sm, d.c_sn, d.c_sb1, d.c_sb2 = c.data_ptr(), c_sm, 1, c_sb[0], c_sb[1]
+    d.dtype_a, d.dtype_b, d.dtype_c = _dt(a), _dt(b), _dt(c)
+    d.alpha = alpha
+    d.accumulate = int(accumulate)
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        d.bias = bias.data_ptr()
+    d.act = act
+    for name, t in (("preact", preact), ("residual", residual), ("dact_aux", dact_aux)):
+        if t is not None:
+            assert t.dtype == c.dtype and t.stride(-1) == 1 and t.stride(-2) == c_sm, name
+            setattr(d, name, t.data_ptr())
+    d.dact = dact
+    d.force_generic = int(force_generic)
+    check(_lib.lib().m3ae_gemm(C.byref(d), _stream()), "m3ae_gemm")
+
+
+def last_gemm_path():
+    return _lib.lib().m3ae_last_gemm_path().decode()
+
+
+def _rows(x):
+    """View x [..., K] as 2-D rows (M, K) without copying; returns (tensor2d, M, K, row_stride)."""
+    K = x.shape[-1]
+    if x.dim() == 2:
+        assert x.stride(1) == 1
+        return x, x.shape[0], K, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    x2 = x.view(-1, K)
+    return x2, x2.shape[0], K, K
+
+
+def mm_nt(x2, ldx, M, w, bias=None, act=ACT_NONE, residual=None, want_preact=False, out_dtype=None, dact_aux=None,
+          dact=ACT_NONE, force_generic=False):
+    """y[M,N] = epi(x2[M,K] . w[N,K]^T)."""
+    N, K = w.shape
+    y = torch.empty((M, N), dtype=out_dtype or x2.dtype, device=x2.device)
+    pre = torch.empty_like(y) if want_preact else None
+    gemm(x2, ldx, 1, w, 1, w.stride(0), y, N, M, N, K, bias=bias, act=act, preact=pre, residual=residual,
+         dact_aux=dact_aux, dact=dact, force_generic=force_generic)
+    return y, pre
+
+
+def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None):
+    """dx[M,K] = dy[M,N] . W[N,K]  (bf16: NT against the transposed shadow; fp32: strided generic)."""
+    M, N = dy.shape
+    wt = getattr(w_param, "m3ae_t", None)
+    if wt is not None:
+        K = wt.shape[0]
+        dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+        gemm(dy, dy.stride(0), 1, wt, 1, wt.stride(0), dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual)
+    else:
+        w = compute_weight(w_param)
+        K = w.shape[1]
+        dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+        gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual)
+    return dx
+
+
+def mm_wgrad(dy, x2, ldx, w_param):
+    """w.grad[N,K] += dy[M,N]^T . x2[M,K]  (fp32 accumulate in place)."""
+    if not w_param.requires_grad:
+        return
+    g = _grad_buf(w_param)
+    M, N = dy.shape
+    K = g.shape[1]
+    gemm(dy, 1, dy.stride(0), x2, ldx, 1, g, g.stride(0), N, K, M, accumulate=True)
+    _done(w_param)
+
+
+def bias_grad(dy, b_param):
+    if b_param is None or not b_param.requires_grad:
+        return
+    g = _grad_buf(b_param)
+    M, N = dy.shape
+    check(_lib.lib().m3ae_colsum(_p(dy), _p(g), M, N, dy.stride(0), _dt(dy), 1, _stream()), "m3ae_colsum")
+    _done(b_param)
+
+
+def act_bwd(dy, pre, act):
+    dx = torch.empty_like(dy)
+    check(_lib.lib().m3ae_act_bwd(_p(dy), _p(pre), _p(dx), dy.numel(), act, _dt(dy), _stream()), "m3ae_act_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Linear / MLP
+# ----------------------------------------------------------------------------------------------------------
+def _members(p):
+    return getattr(p, "members", None) or ([p] if p is not None else [])
+
+
+def _done(p):
+    if grad_ready_hook is not None and p is not None:
+        for m in _members(p):
+            grad_ready_hook(m)
+
+
+def _grad_buf(p):
+    if getattr(p, "members", None) is not None:  # PackedParam: members' grads are adjacent views of the flat buffer
+        g = p.grad
+        if g is None:
+            raise _lib.M3AEHipError("packed parameters need ParamStore-managed gradients")
+        return g
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, dtype=torch.float32)
+    return p.grad
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b + extra_bias) (+ residual).  nn.Linear sites of clip_model.py / bert_model.py /
+    m3ae_module.py.  `weight` / `bias` are Parameters or PackedParams; `anchors` are the underlying Parameters of a
+    PackedParam (graph recording only)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, extra_bias, weight, bias, act, *anchors):
+        x2, M, K, ldx = _rows(x)
+        w = compute_weight(weight)
+        b = None if bias is None else (bias.data if hasattr(bias, "members") else bias.detach())
+        if extra_bias is not None:  # e.g. + modality_type_embeddings row (m3ae_module.py:260-263)
+            b = extra_bias.detach().float() if b is None else b + extra_bias.detach().float()
+        res2 = None
+        if residual is not None:
+            res2 = residual.contiguous().view(M, -1)
+        y, pre = mm_nt(x2, ldx, M, w, bias=b, act=act, residual=res2, want_preact=(act != ACT_NONE))
+        ctx.save_for_backward(x2, pre)
+        ctx.weight, ctx.bias, ctx.act, ctx.ldx = weight, bias, act, ldx
+        ctx.x_shape, ctx.has_res = x.shape, residual is not None
+        ctx.x_needs = x.requires_grad
+        ctx.extra_needs = extra_bias is not None and extra_bias.requires_grad
+        ctx.n_anchor = len(anchors)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre = ctx.saved_tensors
+        N = dy.shape[-1]
+        dy2 = dy.contiguous().view(-1, N)
+        dres = dy if ctx.has_res else None
+        dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
+        mm_wgrad(dz, x2, ctx.ldx, ctx.weight)
+        dextra = None
+        if ctx.extra_needs:
+            dextra = torch.empty(N, dtype=torch.float32, device=dz.device)
+            check(_lib.lib().m3ae_colsum(_p(dz), _p(dextra), dz.shape[0], N, dz.stride(0), _dt(dz), 0, _stream()),
+                  "m3ae_colsum")
+            if ctx.bias is not None and ctx.bias.requires_grad:
+                _grad_buf(ctx.bias).add_(dextra)
+                _done(ctx.bias)
+        else:
+            bias_grad(dz, ctx.bias)
+        dx = None
+        if ctx.x_needs:
+            dx = mm_dgrad(dz, ctx.weight).view(ctx.x_shape)
+        return (dx, dres, dextra, None, None, None) + (None,) * ctx.n_anchor
+
+
+class GatherLinearFn(torch.autograd.Function):
+    """y = act(x[:, 0] W^T + b): Pooler (prediction_heads.py:15-18).  The token-0 rows are addressed in place
+    through the GEMM's row stride; the backward scatters into a zeroed [B, L, D] gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        B, L, D = x.shape
+        xc = x.contiguous()
+        w = compute_weight(weight)
+        y, pre = mm_nt(xc, L * D, B, w, bias=bias, act=act, want_preact=(act != ACT_NONE))
+        ctx.save_for_backward(xc, pre)
+        ctx.weight, ctx.bias, ctx.act = weight, bias, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, pre = ctx.saved_tensors
+        B, L, D = xc.shape
+        dy2 = dy.contiguous()
+        dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
+        mm_wgrad(dz, xc, L * D, ctx.weight)
+        bias_grad(dz, ctx.bias)
+        dx = torch.zeros_like(xc)
+        wt = getattr(ctx.weight, "m3ae_t", None)
+        N = dz.shape[1]
+        if wt is not None:
+            gemm(dz, N, 1, wt, 1, wt.stride(0), dx, L * D, B, D, N)
+        else:
+            w = compute_weight(ctx.weight)
+            gemm(dz, N, 1, w, w.stride(0), 1, dx, L * D, B, D, N)
+        return dx, None, None, None
+
+
+class MLPFn(torch.autograd.Function):
+    """y = act(x W1^T + b1) W2^T + b2 (+ residual).  BertIntermediate + BertOutput.dense (bert_model.py:416-440)
+    and the CLIP mlp (clip_model.py:46-50).  The activation derivative is fused into the dgrad GEMM's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, act):
+        x2, M, K, ldx = _rows(x)
+        g, u = mm_nt(x2, ldx, M, compute_weight(w1), bias=b1, act=act, want_preact=True)
+        res2 = residual.contiguous().view(M, -1) if residual is not None else None
+        y, _ = mm_nt(g, g.stride(0), M, compute_weight(w2), bias=b2, residual=res2)
+        ctx.save_for_backward(x2, u, g)
+        ctx.p = (w1, b1, w2, b2)
+        ctx.act, ctx.ldx, ctx.x_shape, ctx.has_res = act, ldx, x.shape, residual is not None
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, g = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.p
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        dres = dy if ctx.has_res else None
+        mm_wgrad(dy2, g, g.stride(0), w2)
+        bias_grad(dy2, b2)
+        du = mm_dgrad(dy2, w2, dact_aux=u, dact=ctx.act)  # dU = (dY W2) * act'(U)
+        mm_wgrad(du, x2, ctx.ldx, w1)
+        bias_grad(du, b1)
+        dx = mm_dgrad(du, w1).view(ctx.x_shape)
+        return dx, dres, None, None, None, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, extra_bias=None):
+    anchors = tuple(_members(weight)) if hasattr(weight, "members") else ()
+    if hasattr(bias, "members"):
+        anchors = anchors + tuple(bias.members)
+    return LinearFn.apply(x, residual, extra_bias, weight, bias, act, *anchors)
+
+
+def mlp(x, w1, b1, w2, b2, act, residual=None):
+    return MLPFn.apply(x, residual, w1, b1, w2, b2, act)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, rms):
+        xc = x.contiguous()
+        D = xc.shape[-1]
+        M = xc.numel() // D
+        y = torch.empty_like(xc)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        check(_lib.lib().m3ae_layernorm_fwd(_p(xc), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _dt(xc),
+                                            act, int(rms), _stream()), "m3ae_layernorm_fwd")
+        ctx.save_for_backward(xc, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.act, ctx.rms = gamma, beta, act, rms
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, mean, rstd = ctx.saved_tensors
+        D = xc.shape[-1]
+        M = xc.numel() // D
+        dyc = dy.contiguous()
+        dx = torch.empty_like(xc)
+        L = _lib.lib()
+        nblk = L.m3ae_layernorm_bwd_blocks(M)
+        ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=xc.device)
+        gg = _grad_buf(ctx.gamma)
+        gb = _grad_buf(ctx.beta) if ctx.beta is not None else None
+        check(L.m3ae_layernorm_bwd(_p(dyc), _p(xc), _p(ctx.gamma), _p(ctx.beta), _p(mean), _p(rstd), _p(dx), _p(gg),
+                                   _p(gb), _p(ws), M, D, _dt(xc), ctx.act, int(ctx.rms), _stream()),
+              "m3ae_layernorm_bwd")
+        _done(ctx.gamma)
+        _done(ctx.beta)
+        return dx, None, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, act=ACT_NONE, rms=False):
+    return LayerNormFn.apply(x, gamma, beta, eps, act, rms)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------------
+def _attn_desc(B, H, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, dtype):
+    d = AttnDesc()
+    d.B, d.H, d.Lq, d.Lk, d.Dh = B, H, Lq, Lk, Dh
+    d.q, d.q_sb, d.q_sl = q.data_ptr(), q.stride(0), q.stride(1)
+    d.k, d.k_sb, d.k_sl = k.data_ptr(), k.stride(0), k.stride(1)
+    d.v, d.v_sb, d.v_sl = v.data_ptr(), v.stride(0), v.stride(1)
+    d.o, d.o_sb, d.o_sl = o.data_ptr(), o.stride(0), o.stride(1)
+    d.key_mask = key_mask.data_ptr() if key_mask is not None else None
+    d.pos_bias = pos_bias.data_ptr() if pos_bias is not None else None
+    d.scale, d.causal = scale, int(causal)
+    d.lse = lse.data_ptr() if lse is not None else None
+    d.lse_stride = lse_stride
+    d.dtype = dtype
+    return d
+
+
+def _attn_ws(d, backward, device):
+    n = _lib.lib().m3ae_attn_workspace_bytes(C.byref(d), int(backward))
+    if n <= 0:
+        return None
+    ws = torch.empty(n, dtype=torch.uint8, device=device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), n
+    return ws
+
+
+def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causal=False):
+    """q [B,Lq,D] / k,v [B,Lk,D] (last dim contiguous, any batch/token strides) -> o [B,Lq,D], lse."""
+    _need_cuda(q)
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    Dh = D // heads
+    scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
+    o = torch.empty((B, Lq, D), dtype=q.dtype, device=q.device)
+    lse_stride = (Lq + 31) // 32 * 32
+    lse = torch.empty((B, heads, lse_stride), dtype=torch.float32, device=q.device)
+    d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
+    ws = _attn_ws(d, False, q.device)
+    check(_lib.lib().m3ae_attn_fwd(C.byref(d), _stream()), "m3ae_attn_fwd")
+    del ws
+    return o, lse
+
+
+def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bias=None, scale=None, causal=False,
+                  d_pos_bias=None):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    Dh = D // heads
+    scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
+    assert do.stride() == o.stride() and dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+    d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse.shape[-1], _dt(q))
+    delta = torch.empty_like(lse)
+    d.d_o, d.dq, d.dk, d.dv, d.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+    d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
+    ws = _attn_ws(d, True, q.device)
+    check(_lib.lib().m3ae_attn_bwd(C.byref(d), _stream()), "m3ae_attn_bwd")
+    del ws, delta
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """softmax(QK^T / sqrt(dh) + mask) V on a packed [B, L, 3D] projection (rows Q | K | V)."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, heads):
+        D = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        o, lse = attn_forward(q, k, v, heads, key_mask)
+        ctx.save_for_backward(qkv, o, lse, key_mask)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, key_mask = ctx.saved_tensors
+        D = qkv.shape[-1] // 3
+        dqkv = torch.empty_like(qkv)
+        attn_backward(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), dqkv[..., :D],
+                      dqkv[..., D:2 * D], dqkv[..., 2 * D:], ctx.heads, key_mask)
+        return dqkv, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """Q from this stream [B, Lq, D]; packed K | V [B, Lk, 2D] from the other stream (bert_model.py:275-278)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_mask, heads):
+        D = q.shape[-1]
+        o, lse = attn_forward(q, kv[..., :D], kv[..., D:], heads, key_mask)
+        ctx.save_for_backward(q, kv, o, lse, key_mask)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse, key_mask = ctx.saved_tensors
+        D = q.shape[-1]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        attn_backward(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), dq, dkv[..., :D], dkv[..., D:], ctx.heads,
+                      key_mask)
+        return dq, dkv, None, None
+
+
+def self_attention(qkv, key_mask, heads):
+    return SelfAttnFn.apply(qkv, key_mask, heads)
+
+
+def cross_attention(q, kv, key_mask, heads):
+    return CrossAttnFn.apply(q, kv, key_mask, heads)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# embeddings / tokens
+# ----------------------------------------------------------------------------------------------------------
+class RobertaEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, pad_id, dtype):
+        _need_cuda(ids)
+        B, S = ids.shape
+        D = word.shape[1]
+        out = torch.empty((B, S, D), dtype=dtype, device=ids.device)
+        check(_lib.lib().m3ae_roberta_embed_fwd(_p(ids), _p(word), _p(pos), _p(typ), _p(out), B, S, D, pad_id, _dt(out),
+                                                _stream()), "m3ae_roberta_embed_fwd")
+        ctx.save_for_backward(ids)
+        ctx.p, ctx.pad_id = (word, pos, typ), pad_id
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        word, pos, typ = ctx.p
+        B, S = ids.shape
+        D = word.shape[1]
+        d = dout.contiguous()
+        check(_lib.lib().m3ae_roberta_embed_bwd(_p(ids), _p(d), _p(_grad_buf(word)), _p(_grad_buf(pos)),
+                                                _p(_grad_buf(typ)), B, S, D, ctx.pad_id, _dt(d), _stream()),
+              "m3ae_roberta_embed_bwd")
+        for p in (word, pos, typ):
+            _done(p)
+        return None, None, None, None, None, None
+
+
+def roberta_embed(ids, word, pos, typ, pad_id, dtype):
+    return RobertaEmbedFn.apply(ids, word, pos, typ, pad_id, dtype)
+
+
+class VitTokensFn(torch.autograd.Function):
+    """conv1 (k = s = patch, no bias) as im2col + GEMM, prepend class_embedding, optional + positional_embedding
+    (clip_model.py:94-99 / :110-116)."""
+
+    @staticmethod
+    def forward(ctx, img, conv_w, cls, pos, dtype, add_pos):
+        _need_cuda(img)
+        L = _lib.lib()
+        B, _, R, _ = img.shape
+        width, _, P, _ = conv_w.shape
+        g = R // P
+        G = g * g
+        imgc = img.contiguous().float()
+        patches = torch.empty((B * G, 3 * P * P), dtype=dtype, device=img.device)
+        check(L.m3ae_patchify(_p(imgc), _p(patches), B, R, P, _dt(patches), _stream()), "m3ae_patchify")
+        w2 = compute_weight(conv_w).view(width, -1)
+        pe, _ = mm_nt(patches, patches.stride(0), B * G, w2)
+        out = torch.empty((B, G + 1, width), dtype=dtype, device=img.device)
+        posz = pos if add_pos else torch.zeros_like(pos)
+        check(L.m3ae_vit_tokens_fwd(_p(pe), _p(cls), _p(posz), _p(out), B, G, width, _dt(out), _stream()),
+              "m3ae_vit_tokens_fwd")
+        ctx.save_for_backward(patches)
+        ctx.p, ctx.dims, ctx.add_pos = (conv_w, cls, pos), (B, G, width), add_pos
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (patches,) = ctx.saved_tensors
+        conv_w, cls, pos = ctx.p
+        B, G, width = ctx.dims
+        d = dout.contiguous()
+        dpe = torch.empty((B * G, width), dtype=d.dtype, device=d.device)
+        gpos = _grad_buf(pos) if ctx.add_pos else torch.zeros_like(pos)
+        check(_lib.lib().m3ae_vit_tokens_bwd(_p(d), _p(dpe), _p(_grad_buf(cls)), _p(gpos), B, G, width, _dt(d),
+                                             _stream()), "m3ae_vit_tokens_bwd")
+        _done(cls)
+        if ctx.add_pos:
+            _done(pos)
+        if conv_w.requires_grad:
+            g = _grad_buf(conv_w).view(width, -1)
+            gemm(dpe, 1, dpe.stride(0), patches, patches.stride(0), 1, g, g.stride(0), width, g.shape[1], B * G,
+                 accumulate=True)
+            _done(conv_w)
+        return None, None, None, None, None, None
+
+
+def vit_tokens(img, conv_w, cls, pos, dtype, add_pos=True):
+    return VitTokensFn.apply(img, conv_w, cls, pos, dtype, add_pos)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------------------
+class BCELossFn(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(x, z) * z.shape[1]  (objectives.py:201)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        x = logits.contiguous()
+        B, Cc = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        check(_lib.lib().m3ae_bce_logits(_p(x), _p(targets), _p(loss), _p(dx), B, Cc, 1.0, _dt(x), _stream()),
+              "m3ae_bce_logits")
+        ctx.save_for_backward(dx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g.to(dx.dtype), None
+
+
+def bce_with_logits_loss(logits, targets):
+    return BCELossFn.apply(logits, targets)
+
+
+class XentFn(torch.autograd.Function):
+    """F.cross_entropy(logits, labels, ignore_index=-100) (objectives.py:19-23, :101)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        x = logits.contiguous().view(-1, logits.shape[-1])
+        rows, Cc = x.shape
+        lab = labels.contiguous().view(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = torch.empty(4, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        check(_lib.lib().m3ae_xent(_p(x), _p(lab), _p(loss), _p(dx), _p(ws), rows, Cc, Cc, 1.0, _dt(x), _stream()),
+              "m3ae_xent")
+        ctx.save_for_backward(dx)
+        ctx.shape = logits.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return (dx * g.to(dx.dtype)).view(ctx.shape), None
+
+
+def cross_entropy(logits, labels):
+    return XentFn.apply(logits, labels)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# row gather (MIM masking) -- differentiable in the source
+# ----------------------------------------------------------------------------------------------------------
+class GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        s2 = src.contiguous().view(-1, src.shape[-1])
+        out = torch.empty((idx.numel(), s2.shape[1]), dtype=src.dtype, device=src.device)
+        check(_lib.lib().m3ae_gather_rows(_p(s2), _p(idx), _p(out), idx.numel(), s2.shape[1], _dt(s2), _stream()),
+              "m3ae_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.shape = src.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        d = dout.contiguous()
+        dsrc = torch.zeros(ctx.shape, dtype=d.dtype, device=d.device)
+        check(_lib.lib().m3ae_scatter_add_rows(_p(d), _p(idx), _p(dsrc), idx.numel(), d.shape[1], _dt(d), _stream()),
+              "m3ae_scatter_add_rows")
+        return dsrc, None
+
+
+def gather_rows(src, flat_idx):
+    return GatherRowsFn.apply(src, flat_idx)
+
+
+def selftest():
+    out = torch.zeros(8 + 256, dtype=torch.int32, device="cuda")
+    check(_lib.lib().m3ae_selftest(_p(out), _stream()), "m3ae_selftest")
+    return out[:6].cpu().tolist()

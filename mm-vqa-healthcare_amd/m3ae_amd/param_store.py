@@ -1,0 +1,211 @@
+"""Flat parameter / gradient / optimizer-state storage laid out for MI355X (288 GB HBM3E: everything resident).
+
+All trainable parameters live in ONE fp32 buffer ordered by optimizer group (m3ae_utils.py:135-204's six groups),
+each tensor 64-element aligned, with `param.data` and `param.grad` re-pointed to views of the flat buffers:
+  * AdamW is one fused kernel launch per group segment (6 launches instead of ~670 per-tensor updates);
+  * the gradient all-reduce operates on contiguous byte ranges of the flat gradient buffer (m3ae_amd/ddp.py);
+  * query/key/value weights of one attention block are adjacent, so the packed [3D, D] (or [2D, D]) projection the
+    kernels want is a zero-copy view (PackedParam) while state_dict names stay the reference's;
+  * in bf16 mode the AdamW kernel also writes the bf16 shadow the forward GEMMs read (same offsets), and each GEMM
+    weight unit gets a transposed bf16 copy [K, N] so dgrad is the same K-contiguous "NT" MFMA kernel.
+Parameters that never receive a gradient (CLIP text-tower leftovers, RoBERTa pooler) keep their names and
+values but are left out of the gradient / optimizer / all-reduce buffers.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+ALIGN = 64
+
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
+            "norm2.bias", "norm2.weight"]
+HEAD_NAMES = ["mlm_head", "mim_head", "itm_head", "vqa_head", "cls_head", "irtr_head"]
+NEVER_USED = ("vision_encoder.positional_embedding", "vision_encoder.token_embedding.weight",
+              "vision_encoder.ln_final.weight", "vision_encoder.ln_final.bias",
+              "language_encoder.pooler.dense.weight", "language_encoder.pooler.dense.bias")
+
+
+def param_group_of(name):
+    """Index 0..5 of the reference's six AdamW groups (m3ae_utils.py:135-204), by substring match on the name."""
+    nd = any(k in name for k in NO_DECAY)
+    hd = any(k in name for k in HEAD_NAMES)
+    mm = "multi_modal" in name
+    if not hd and not mm:
+        return 1 if nd else 0
+    if hd and not mm:
+        return 3 if nd else 2
+    if mm and not hd:
+        return 5 if nd else 4
+    return -1
+
+
+def group_hparams(cfg):
+    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    lh, lm = cfg["lr_multiplier_head"], cfg["lr_multiplier_multi_modal"]
+    return [(lr, wd), (lr, 0.0), (lr * lh, wd), (lr * lh, 0.0), (lr * lm, wd), (lr * lm, 0.0)]
+
+
+class PackedParam:
+    """Zero-copy [sum(N_i), K] view over adjacent parameters (q|k|v weights or biases) of the flat buffers."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        m0 = self.members[0]
+        rows = sum(m.shape[0] for m in self.members)
+        self.shape = (rows,) + tuple(m0.shape[1:])
+        self.m3ae_t = None
+        self._check_adjacent()
+
+    def _check_adjacent(self):
+        off = 0
+        m0 = self.members[0]
+        for m in self.members:
+            if m.data_ptr() != m0.data_ptr() + off * m0.element_size():
+                raise _lib.M3AEHipError("PackedParam members are not adjacent: apply ParamStore before forward")
+            off += m.numel()
+
+    def _view(self, t0):
+        stride = (self.shape[1], 1) if len(self.shape) == 2 else (1,)
+        return t0.as_strided(self.shape, stride)
+
+    @property
+    def data(self):
+        return self._view(self.members[0].data)
+
+    @property
+    def m3ae_c(self):
+        m0 = self.members[0]
+        return self._view(getattr(m0, "m3ae_c", m0.data))
+
+    @property
+    def requires_grad(self):
+        return all(m.requires_grad for m in self.members)
+
+    @property
+    def grad(self):
+        g0 = self.members[0].grad
+        return None if g0 is None else self._view(g0)
+
+
+class ParamStore:
+    def __init__(self, module, cfg, device, compute_dtype=torch.bfloat16, weight_units=None, frozen=()):
+        self.module, self.cfg, self.device, self.compute_dtype = module, cfg, device, compute_dtype
+        named = [(n, p) for n, p in module.named_parameters()]
+        self.names = {id(p): n for n, p in named}
+        groups = [[] for _ in range(7)]  # 0..5 optimizer groups, 6 = no-grad
+        for n, p in named:
+            gi = param_group_of(n)
+            unused = any(n == u or n.endswith("." + u) for u in NEVER_USED) or any(n.startswith(f) for f in frozen)
+            if unused or gi < 0 or not p.requires_grad:
+                groups[6].append((n, p))
+            else:
+                groups[gi].append((n, p))
+        self.groups = groups
+        # offsets
+        self.offset, self.segments = {}, []
+        off = 0
+        for gi, g in enumerate(groups):
+            start = off
+            for n, p in g:
+                self.offset[id(p)] = off
+                off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.segments.append((start, off))
+        self.total = off
+        self.trainable_end = self.segments[5][1]
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.trainable_end, dtype=torch.float32, device=device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device) \
+            if compute_dtype == torch.bfloat16 else None
+        for gi, g in enumerate(groups):
+            for n, p in g:
+                o = self.offset[id(p)]
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                if gi < 6:
+                    p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                else:
+                    p.requires_grad_(False)
+                    p.grad = None
+                if self.shadow is not None:
+                    p.m3ae_c = self.shadow[o:o + p.numel()].view(p.shape)
+        self.step_count = 0
+        # weight units: GEMM weights that need a transposed bf16 copy for dgrad
+        self.units = list(weight_units() if callable(weight_units) else (weight_units or []))
+        self._t_bufs = []
+        if self.shadow is not None:
+            for u in self.units:
+                shp = u.shape
+                rows, cols = shp[0], int(math.prod(shp[1:]))
+                t = torch.empty((cols, rows), dtype=torch.bfloat16, device=device)
+                u.m3ae_t = t
+                self._t_bufs.append((u, rows, cols, t))
+        self.sync_shadows()
+
+    # ---- shadows -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sync_shadows(self, cast=True):
+        """Refresh bf16 shadows from the fp32 masters (after load_state_dict / manual edits), and the transposed
+        copies of every GEMM weight unit.  After an optimizer step only the transposes are needed (cast=False)."""
+        if self.shadow is None:
+            return
+        L = _lib.lib()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if cast:
+            _lib.check(L.m3ae_cast(C.c_void_p(self.flat.data_ptr()), C.c_void_p(self.shadow.data_ptr()), self.total,
+                                   _lib.F32, _lib.BF16, s), "m3ae_cast")
+        for u, rows, cols, t in self._t_bufs:
+            src = u.data
+            _lib.check(L.m3ae_cast_transpose(C.c_void_p(src.data_ptr()), None, C.c_void_p(t.data_ptr()), rows, cols, s),
+                       "m3ae_cast_transpose")
+
+    # ---- optimizer -----------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def lr_factor(self, step, max_steps):
+        """transformers get_polynomial_decay_schedule_with_warmup (m3ae_utils.py:232-238), lr_init-relative."""
+        cfg = self.cfg
+        warm = cfg["warmup_steps"]
+        if isinstance(warm, float):
+            warm = int(max_steps * warm)
+        lr_init, lr_end, power = cfg["learning_rate"], cfg["end_lr"], cfg["decay_power"]
+        if step < warm:
+            return float(step) / float(max(1, warm))
+        if step > max_steps:
+            return lr_end / lr_init
+        pct = 1 - (step - warm) / (max_steps - warm)
+        return ((lr_init - lr_end) * pct ** power + lr_end) / lr_init
+
+    @torch.no_grad()
+    def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None):
+        """One AdamW step over the six group segments (m3ae_utils.py:206; transformers-4.6.0 AdamW semantics,
+        betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step."""
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.grad)
+            self.exp_avg_sq = torch.zeros_like(self.grad)
+        if lr_factor is None:
+            max_steps = max_steps or self.cfg["max_steps"]
+            lr_factor = self.lr_factor(self.step_count, max_steps)
+        self.step_count += 1
+        L = _lib.lib()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for gi, (lr, wd) in enumerate(group_hparams(self.cfg)):
+            a, b = self.segments[gi]
+            if b <= a:
+                continue
+            es = 4
+            sh = C.c_void_p(self.shadow.data_ptr() + a * 2) if self.shadow is not None else None
+            _lib.check(L.m3ae_adamw(C.c_void_p(self.flat.data_ptr() + a * es), C.c_void_p(self.grad.data_ptr() + a * es),
+                                    C.c_void_p(self.exp_avg.data_ptr() + a * es),
+                                    C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, lr * lr_factor, 0.9,
+                                    0.98, 1e-8, wd, self.step_count, grad_scale, s), "m3ae_adamw")
+        self.sync_shadows(cast=False)
+
+    def group_names(self):
+        return [[n for n, _ in g] for g in self.groups[:6]]

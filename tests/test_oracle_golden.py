@@ -1,0 +1,96 @@
+"""CPU: pin the oracle (oracle/m3ae_oracle.py) against fixtures captured from the reference's own modules
+(oracle/make_golden.py; tests/golden/*.npz).  No GPU, no /root/reference at run time."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import m3ae_oracle as O
+from oracle_util import (full_batch, finetune_vqa_rad_config, load_golden, make_sd, oracle_cfg, tiny_batch, tiny_config)
+
+
+def _grad_check(sd, g, rtol=2e-4):
+    names, ref = g["grad_names"].tolist(), g["grad_norm"]
+    gnorm = float(g["global_grad_norm"])
+    for n, r in zip(names, ref):
+        mine = sd[n].grad.double().norm().item()
+        # key.bias gradients are identically zero in exact arithmetic (softmax shift invariance): absolute floor
+        assert abs(mine - r) <= rtol * r + 1e-7 * gnorm, (n, mine, r)
+    assert sorted(n for n in sd if torch.is_floating_point(sd[n]) and sd[n].grad is None) == sorted(g["nograd_names"].tolist())
+
+
+def test_tiny_vqa_forward_backward_matches_reference():
+    cfg = tiny_config()
+    sd = make_sd(cfg, requires_grad=True)
+    g = load_golden("tiny_vqa.npz")
+    trail = {}
+    b = tiny_batch()
+    out = O.infer(sd, oracle_cfg(cfg), b["image"][0], b["text_ids"], b["text_masks"], trail=trail)
+    for k in ("text_enc", "image_enc", "fusion_text_0", "fusion_image_0", "fusion_text_1", "fusion_image_1"):
+        np.testing.assert_allclose(trail[k].detach().numpy(), g["trail_" + k], rtol=1e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(out["multi_modal_text_feats"].detach().numpy(), g["text_feats"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["multi_modal_image_feats"].detach().numpy(), g["image_feats"], rtol=1e-4, atol=2e-5)
+    loss, logits, out = O.training_loss(sd, oracle_cfg(cfg), b)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["multi_modal_cls_feats"].detach().numpy(), g["cls_feats"], rtol=1e-4, atol=1e-6)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    _grad_check(sd, g)
+    for k in g.files:
+        if k.startswith("grad::"):
+            ref = g[k]
+            np.testing.assert_allclose(sd[k[6:]].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max() + 1e-9, err_msg=k)
+
+
+def test_tiny_pretrain_heads_match_reference():
+    cfg = tiny_config(loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0}, mim_layer=1,
+                      mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
+    sd = make_sd(cfg)
+    from m3ae_amd.modules.prediction_heads import get_2d_sincos_pos_embed
+    sd["mim_head.decoder_pos_embed"] = torch.from_numpy(get_2d_sincos_pos_embed(128, 4, True)).float().unsqueeze(0)
+    g = load_golden("tiny_pretrain.npz")
+    b = tiny_batch(pretrain=True)
+    oc = oracle_cfg(cfg)
+    img = b["image"][0]
+    out = O.infer(sd, oc, img, b["text_ids_mlm"], b["text_masks"])
+    logits = O.mlm_head(sd, out["multi_modal_text_feats"])
+    np.testing.assert_allclose(logits.numpy(), g["mlm_logits"], rtol=1e-4, atol=2e-5)
+    assert abs(O.mlm_loss(logits, b["text_labels_mlm"]).item() - float(g["mlm_loss"])) < 1e-5 * float(g["mlm_loss"])
+    out = O.infer(sd, oc, img, b["text_ids"], b["text_masks"], mim_noise=b["mim_noise"])
+    np.testing.assert_array_equal(out["mim_ids_restore"].numpy(), g["mim_ids_restore"])
+    np.testing.assert_array_equal(out["mim_masks"].numpy(), g["mim_masks"])
+    np.testing.assert_allclose(out["multi_modal_image_feats"].numpy(), g["mim_image_feats"], rtol=1e-4, atol=2e-5)
+    pred = O.mim_head(sd, out["multi_modal_image_feats_1"], out["mim_ids_restore"], 2)
+    np.testing.assert_allclose(pred.numpy(), g["mim_pred"], rtol=1e-4, atol=2e-5)
+    assert abs(O.mim_loss(pred, img, out["mim_masks"], 16).item() - float(g["mim_loss"])) < 1e-5
+    out = O.infer(sd, oc, img, b["text_ids"], b["text_masks"])
+    il = O.itm_head(sd, out["multi_modal_cls_feats"])
+    np.testing.assert_allclose(il.numpy(), g["itm_logits"], rtol=1e-4, atol=1e-6)
+
+
+def test_param_groups_and_schedule_match_reference():
+    g = load_golden("tiny_vqa.npz")
+    for n, gi in zip(g["group_names"].tolist(), g["group_index"].tolist()):
+        assert O.param_group_of(n) == gi, n
+    cfg = tiny_config()
+    lr = cfg["learning_rate"]
+    np.testing.assert_allclose(g["group_lr"], [lr, lr, lr * 100, lr * 100, lr * 5, lr * 5], rtol=1e-6)
+    np.testing.assert_allclose(g["group_wd"], [0.01, 0, 0.01, 0, 0.01, 0])
+    warm = int(cfg["max_steps"] * cfg["warmup_steps"])
+    for step, row in enumerate(g["sched_lrs"]):
+        f = O.poly_lr_factor(step, warm, cfg["max_steps"], lr, cfg["end_lr"], cfg["decay_power"])
+        np.testing.assert_allclose(row, np.array(g["group_lr"]) * f, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.slow
+def test_full_size_forward_backward_matches_reference():
+    """configs[0]: M3AE-base dims (ViT-B/16 @384 + RoBERTa-base + 6 fusion layers), B = 2, fp32, CPU."""
+    torch.set_num_threads(8)
+    cfg = finetune_vqa_rad_config()
+    sd = make_sd(cfg, requires_grad=True)
+    g = load_golden("full_vqa.npz")
+    loss, logits, out = O.training_loss(sd, oracle_cfg(cfg), full_batch())
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-5)  # north_star tolerance
+    np.testing.assert_allclose(out["multi_modal_cls_feats"].detach().numpy(), g["cls_feats"], rtol=1e-3, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    _grad_check(sd, g, rtol=1e-3)
