@@ -1,0 +1,168 @@
+"""GPU: the whole hot path (M3AETransformerSS.infer -> vqa_head -> BCE -> backward -> AdamW) through the C ABI
+against (a) the CPU oracle on the same seeded inputs and (b) the committed reference fixtures.
+
+Tolerances (stated per north_star): parity mode (fp32) logits rtol 1e-3 vs the reference fixtures, gradient norms
+rtol 2e-3; perf mode (bf16 storage, fp32 accumulate / statistics / softmax) is held to bf16-appropriate bounds:
+logits atol 0.05 (|logits| <= 0.7), loss rtol 2e-3, global grad-norm rtol 3e-2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from m3ae_amd import synth  # noqa: E402
+from m3ae_amd.modules import M3AETransformerSS  # noqa: E402
+from oracle import m3ae_oracle as O  # noqa: E402
+from oracle_util import (finetune_vqa_rad_config, full_batch, load_golden, make_sd, oracle_cfg, tiny_batch,  # noqa: E402
+                         tiny_config)
+
+
+def to_dev(batch, dev="cuda"):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(dev)
+        elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            out[k] = [t.to(dev) for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+def build(cfg, dtype):
+    m = M3AETransformerSS(cfg)
+    synth.fill_deterministic(m)
+    m.finalize("cuda", dtype)
+    m.eval()
+    return m
+
+
+def grad_report(m, g, rtol, floor):
+    names, ref = g["grad_names"].tolist(), g["grad_norm"]
+    gn = float(g["global_grad_norm"])
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n, r in zip(names, ref):
+        mine = params[n].grad.double().norm().item()
+        err = abs(mine - r)
+        if err > rtol * r + floor * gn:
+            rel = err / (r + 1e-30)
+            if rel > worst[0]:
+                worst = (rel, f"{n}: {mine:.6e} vs {r:.6e}")
+    return worst
+
+
+def test_tiny_fp32_parity_against_reference_fixture_and_oracle():
+    cfg = tiny_config(compute_dtype="fp32")
+    m = build(cfg, torch.float32)
+    g = load_golden("tiny_vqa.npz")
+    b = to_dev(tiny_batch())
+    out = m.infer(b)
+    np.testing.assert_allclose(out["multi_modal_text_feats"].detach().cpu().numpy(), g["text_feats"], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(out["multi_modal_image_feats"].detach().cpu().numpy(), g["image_feats"], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(out["multi_modal_cls_feats"].detach().cpu().numpy(), g["cls_feats"], rtol=1e-3, atol=1e-5)
+    m.store.zero_grad()
+    m.set_task()
+    ret = m(b)
+    np.testing.assert_allclose(ret["vqa_logits"].detach().cpu().numpy(), g["logits"], rtol=1e-3, atol=1e-5)
+    loss = ret["vqa_loss"]
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    worst = grad_report(m, g, 2e-3, 1e-6)
+    assert worst[0] == 0.0, worst
+    params = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad::"):
+            ref = g[k]
+            np.testing.assert_allclose(params[k[6:]].grad.cpu().numpy(), ref, rtol=5e-3,
+                                       atol=1e-4 * np.abs(ref).max() + 1e-9, err_msg=k)
+    # the oracle agrees with the fixture on the same inputs (checked on CPU in test_oracle_golden); spot-check here
+    sd = make_sd(cfg)
+    lo, logits_o, _ = O.training_loss(sd, oracle_cfg(cfg), tiny_batch())
+    np.testing.assert_allclose(ret["vqa_logits"].detach().cpu().numpy(), logits_o.numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_tiny_bf16_perf_mode_within_bf16_bounds():
+    cfg = tiny_config(compute_dtype="bf16")
+    m = build(cfg, torch.bfloat16)
+    g = load_golden("tiny_vqa.npz")
+    b = to_dev(tiny_batch())
+    m.store.zero_grad()
+    m.set_task()
+    ret = m(b)
+    logits = ret["vqa_logits"].detach().float().cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() < 0.05, np.abs(logits - g["logits"]).max()
+    loss = ret["vqa_loss"]
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"])
+    loss.backward()
+    names, ref = g["grad_names"].tolist(), g["grad_norm"]
+    params = dict(m.named_parameters())
+    mine = np.array([params[n].grad.double().norm().item() for n in names])
+    gn = np.sqrt((mine ** 2).sum())
+    assert abs(gn - float(g["global_grad_norm"])) < 3e-2 * float(g["global_grad_norm"]), (gn, float(g["global_grad_norm"]))
+    big = ref > 1e-3 * ref.max()
+    rel = np.abs(mine[big] - ref[big]) / ref[big]
+    assert rel.max() < 0.15, (rel.max(), np.array(names)[big][rel.argmax()])
+
+
+def test_tiny_pretrain_objectives_fp32():
+    cfg = tiny_config(compute_dtype="fp32", loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0},
+                      mim_layer=1, mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
+    m = build(cfg, torch.float32)
+    g = load_golden("tiny_pretrain.npz")
+    b = to_dev(tiny_batch(pretrain=True))
+    from m3ae_amd.modules import objectives
+    r = objectives.compute_mlm(m, b)
+    np.testing.assert_allclose(r["mlm_logits"].detach().cpu().numpy(), g["mlm_logits"], rtol=1e-3, atol=1e-4)
+    assert abs(r["mlm_loss"].item() - float(g["mlm_loss"])) < 1e-4 * float(g["mlm_loss"])
+    r = objectives.compute_mim(m, b)
+    np.testing.assert_allclose(r["mim_logits"].detach().cpu().numpy(), g["mim_pred"], rtol=1e-3, atol=1e-4)
+    assert abs(r["mim_loss"].item() - float(g["mim_loss"])) < 1e-4
+    r = objectives.compute_itm(m, b, torch.tensor([1.0, 1.0]))  # un-swapped images, as in the fixture
+    np.testing.assert_allclose(r["itm_logits"].detach().cpu().numpy(), g["itm_logits"], rtol=1e-3, atol=1e-5)
+    m.store.zero_grad()
+    loss = m.training_step(b)
+    loss.backward()
+    assert torch.isfinite(m.store.grad).all()
+
+
+def test_full_size_fp32_logits_within_rtol_1e3_of_reference():
+    """configs[1] dims, B = 2, parity mode: north_star's "logits within rtol 1e-3 of the reference"."""
+    cfg = finetune_vqa_rad_config(compute_dtype="fp32")
+    m = build(cfg, torch.float32)
+    g = load_golden("full_vqa.npz")
+    b = to_dev(full_batch())
+    m.store.zero_grad()
+    m.set_task()
+    ret = m(b)
+    np.testing.assert_allclose(ret["vqa_logits"].detach().cpu().numpy(), g["logits"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ret["multi_modal_cls_feats"].detach().cpu().numpy(), g["cls_feats"], rtol=1e-3, atol=1e-5)
+    loss = ret["vqa_loss"]
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    worst = grad_report(m, g, 2e-3, 1e-6)
+    assert worst[0] == 0.0, worst
+    gn = m.store.grad.double().norm().item()
+    assert abs(gn - float(g["global_grad_norm"])) < 1e-3 * float(g["global_grad_norm"])
+
+
+def test_full_size_bf16_step_and_optimizer():
+    """configs[1] perf mode: one full training step (fwd + bwd + fused AdamW); loss close to the fp32 reference,
+    parameters move, shadows stay in sync."""
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    m = build(cfg, torch.bfloat16)
+    g = load_golden("full_vqa.npz")
+    b = to_dev(full_batch())
+    m.store.zero_grad()
+    loss = m.training_step(b)
+    assert abs(loss.item() - float(g["loss"])) < 3e-3 * float(g["loss"])
+    loss.backward()
+    gn = m.store.grad.double().norm().item()
+    assert abs(gn - float(g["global_grad_norm"])) < 5e-2 * float(g["global_grad_norm"]), (gn, float(g["global_grad_norm"]))
+    before = m.store.flat.clone()
+    m.store.adamw_step(max_steps=1000, lr_factor=1.0)
+    delta = (m.store.flat - before)[: m.store.trainable_end]
+    assert torch.isfinite(delta).all() and delta.abs().max().item() > 0
+    w = m.vqa_head[3].weight
+    assert torch.equal(w.m3ae_c, w.data.to(torch.bfloat16))
+    assert torch.equal(w.m3ae_t, w.data.to(torch.bfloat16).t().contiguous())
