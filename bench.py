@@ -1,0 +1,246 @@
+"""bench.py -- image-question pairs/s of the M3AE Med-VQA fine-tuning step on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch resident in HBM: forward (ViT-B/16 @384 -> RoBERTa-base
+-> 6 co-attention layers -> poolers -> vqa_head -> BCE), backward, bucketed gradient all-reduce (N > 1) and the
+fused AdamW update, bf16 storage / fp32 accumulation (configs[1] of BASELINE.json).  Per-GPU batch is fixed as N
+grows (weak scaling, as DDP shards a global batch).  Rank 0 prints ONE JSON line.
+
+Extra legs after the timed region (rank 0):
+  roofline     -- every GEMM / attention launch of two further steps is bracketed by HIP events on its launch
+                  stream; `roofline` reports the dominant kernel (the bf16 MFMA "NT" GEMM): algorithmic FLOPs of
+                  its launches / their summed durations vs the 2.5 PFLOP/s dense bf16 peak, plus the fused
+                  cross-attention forward (north_star's kernel) at the batch it ran.
+  cpu_baseline -- the oracle (CPU restatement of the reference path, fp32) timed on this node's host cores on a
+                  bounded sample (B = 2, fwd + bwd), N = 1 only.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "mm-vqa-healthcare_amd"), ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+FWD_GFLOP_PER_SAMPLE = 183.8
+STEP_GFLOP_PER_SAMPLE = 551.3  # fwd + bwd
+XATTN_FWD_GFLOP_PER_SAMPLE = 17.922  # 6 layers x 2 directions, projections + SDPA
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress to stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("M3AE_CPU_THREADS", 16))))
+
+
+def to_dev(batch, dev):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(dev)
+        elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            out[k] = [t.to(dev) for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("M3AE_BENCH_BATCH", 64)), help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from m3ae_amd import ops, synth
+    from m3ae_amd.config import finetune_vqa_rad_config
+    from m3ae_amd.ddp import FlatGradReducer
+    from m3ae_amd.modules import M3AETransformerSS
+    from m3ae_amd.modules.objectives import build_vqa_targets
+
+    torch.set_num_threads(host_cores())
+    log(f"rank {rank}/{world} on {dev}: building model")
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    model = M3AETransformerSS(cfg)
+    synth.fill_deterministic(model)  # random-init weights of the named architecture (no checkpoints offline)
+    model.finalize(dev, torch.bfloat16)
+    model.eval()  # dropout is not applied on this path
+    store = model.store
+    reducer = FlatGradReducer(store).attach()
+
+    log("model resident; generating synthetic batch")
+    B = args.batch
+    batch = to_dev(synth.synthetic_batch(B, text_len=32, image_size=384, rank=rank), dev)
+    batch["vqa_targets"] = build_vqa_targets(batch, cfg["vqa_label_size"], dev)
+    max_steps = args.steps + args.warmup + 16
+
+    def step():
+        store.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        reducer.finish()
+        store.adamw_step(max_steps=max_steps, grad_scale=reducer.grad_scale)
+        return loss
+
+    for i in range(args.warmup):
+        loss = step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done, loss {loss.item():.4f}")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    final_loss = loss.item()
+    log(f"timed region: {ms_per_step:.2f} ms/step, {value:.1f} pairs/s")
+
+    roofline, xattn, kern_table = None, None, None
+    if rank == 0 and not args.no_roofline:
+        log("roofline leg")
+        ops.PROFILE = []
+        reducer.detach()
+        for _ in range(2):
+            store.zero_grad()
+            model.training_step(batch).backward()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for kind, dims, e0, e1 in recs:
+            ms = e0.elapsed_time(e1)
+            if kind.startswith("gemm"):
+                M, N, K, nb = dims
+                fl = 2.0 * M * N * K * nb
+            else:
+                Bq, H, Lq, Lk, Dh = dims
+                fl = 4.0 * Bq * H * Lq * Lk * Dh * (1.0 if kind == "attn_fwd" else 2.5)
+            a = agg.setdefault(kind, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += fl
+        kern_table = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+                      for k, v in agg.items() if v[1] > 0}
+        dom = "gemm:mfma_nt"
+        if dom in agg:
+            n, ms, fl = agg[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": round(ach, 1),
+                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                        "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
+                        "flops_per_launch": fl / n}
+        # fused cross-attention forward (all 6 layers, both directions), HIP events around the sub-blocks
+        with torch.no_grad():
+            dt_ = torch.bfloat16
+            x = torch.randn(B, 32, 768, device=dev).to(dt_)
+            y = torch.randn(B, 577, 768, device=dev).to(dt_)
+            mt = model.language_encoder.get_extended_attention_mask(batch["text_masks"]).contiguous()
+
+            def xattn_all():
+                for tl, il in zip(model.multi_modal_language_layers, model.multi_modal_vision_layers):
+                    tl.crossattention(x, None, y, None)
+                    il.crossattention(y, None, x, mt)
+            xattn_all()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                xattn_all()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            tf = XATTN_FWD_GFLOP_PER_SAMPLE * B / 1e3
+            xattn = {"batch": B, "ms": round(ms, 3), "tflop": round(tf, 3), "achieved": round(tf / (ms * 1e-3), 1),
+                     "unit": "TFLOP/s", "frac": round(tf / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),
+                     "note": "includes the output-dense residual + LayerNorm kernels of each sub-block"}
+        reducer.attach()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import m3ae_oracle as O
+        from oracle_util import make_sd, oracle_cfg
+        log("cpu_baseline leg (oracle on host cores)")
+        torch.set_num_threads(host_cores())
+        sd = make_sd(cfg, requires_grad=True)
+        cb = synth.synthetic_batch(2, text_len=32, image_size=384, rank=0)
+        oc = oracle_cfg(cfg)
+        times = []
+        for i in range(3):
+            for p in sd.values():
+                p.grad = None
+            tt = time.perf_counter()
+            l, _, _ = O.training_loss(sd, oc, cb)
+            l.backward()
+            times.append(time.perf_counter() - tt)
+            log(f"cpu_baseline iter {i}: {times[-1]:.1f}s")
+        best = min(times[1:])
+        cpu = {"value": round(2 / best, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "B=2 fwd+bwd fp32 (no optimizer), 1 warm-up + 2 timed, oracle/m3ae_oracle.py on PyTorch-CPU"}
+
+    if rank == 0:
+        line = {
+            "metric": "image-question pairs/sec, M3AE-base fine-tune step (fwd+bwd+AdamW) @384px",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: M3AE-base (ViT-B/16 + RoBERTa-base + 6 co-attention layers) VQA-RAD "
+                                   "classification fine-tune, 384x384, 32 text tokens, 498 answers",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "dropout": "off (eval-mode semantics)", "weights": "random-init (synthetic, deterministic)"},
+            "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1),
+            "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(final_loss, 4),
+            "roofline": roofline, "cross_attention_fwd": xattn, "kernels": kern_table, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

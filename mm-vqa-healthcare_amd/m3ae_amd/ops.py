@@ -15,6 +15,23 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, check)
 
 grad_ready_hook = None  # callable(param) set by the DDP reducer
+PROFILE = None  # when a list: every GEMM / attention launch is bracketed by HIP events on the launch stream
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, kind, dims):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((kind, dims, e0, e1))
 
 
 def _dt(t):
@@ -69,7 +86,10 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
             setattr(d, name, t.data_ptr())
     d.dact = dact
     d.force_generic = int(force_generic)
+    e0 = _prof_begin()
     check(_lib.lib().m3ae_gemm(C.byref(d), _stream()), "m3ae_gemm")
+    if e0 is not None:
+        _prof_end(e0, "gemm:" + last_gemm_path(), (M, N, K, batch[0] * batch[1]))
 
 
 def last_gemm_path():
@@ -369,7 +389,9 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     lse = torch.empty((B, heads, lse_stride), dtype=torch.float32, device=q.device)
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
     ws = _attn_ws(d, False, q.device)
+    e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_fwd(C.byref(d), _stream()), "m3ae_attn_fwd")
+    _prof_end(e0, "attn_fwd", (B, heads, Lq, Lk, Dh))
     del ws
     return o, lse
 
@@ -386,7 +408,9 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     d.d_o, d.dq, d.dk, d.dv, d.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
     ws = _attn_ws(d, True, q.device)
+    e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_bwd(C.byref(d), _stream()), "m3ae_attn_bwd")
+    _prof_end(e0, "attn_bwd", (B, heads, Lq, Lk, Dh))
     del ws, delta
 
 
