@@ -164,6 +164,15 @@ def main():
             a[0] += 1
             a[1] += ms
             a[2] += fl
+        shp = {}
+        for kind, dims, e0, e1 in recs:
+            if kind.startswith("gemm:mfma"):
+                a = shp.setdefault((kind, dims[:3]), [0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+        for (kind, (M_, N_, K_)), (n_, ms_) in sorted(shp.items(), key=lambda kv: -kv[1][1])[:16]:
+            log(f"  {kind:12s} M={M_:6d} N={N_:5d} K={K_:6d}: {n_:4d} launches, avg {ms_ / n_ * 1e3:8.1f} us, "
+                f"{2.0 * M_ * N_ * K_ * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s, total {ms_ / 2:7.2f} ms/step")
         kern_table = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                       for k, v in agg.items() if v[1] > 0}
         dom = "gemm:mfma_nt"

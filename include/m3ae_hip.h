@@ -175,8 +175,12 @@ int m3ae_gather_rows(const void* in, const int64_t* idx, void* out, int64_t n_ou
 int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void* d_in, int64_t n_out, int64_t D, int dtype,
                           void* stream);
 
+/* tuning knobs for A/B measurements (process-global, not part of the data path contract).
+ * key 0: NT GEMM tile variant (0 = 128x128, 2-stage, 2 workgroups/CU; 1 = 256x128, 3-stage ring, 8 waves). */
+int m3ae_set_tuning(int key, int value);
+
 /* self-test of hardware idioms the kernels rely on (MFMA fragment maps, ds_read_b64_tr_b16, accumulator-as-
- * operand k-order).  out: int32[8] device buffer, out[0] = number of mismatches. */
+ * operand k-order).  out: int32[8 + 256] device buffer (tail = scratch), out[0] = number of mismatches. */
 int m3ae_selftest(int32_t* out, void* stream);
 
 #ifdef __cplusplus

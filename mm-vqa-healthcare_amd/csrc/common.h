@@ -64,6 +64,45 @@ DEVINL float act_bwd(float x, int act) {
     }
 }
 
+// ---- fast erf-GELU for the bf16 MFMA epilogues -------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution): one v_exp + one v_rcp + 6 FMAs,
+// instead of libm erff (~50 instructions per element, which made the K = 768 GELU GEMMs epilogue-bound).
+// The same exp(-x^2/2) term serves the Gaussian pdf of the derivative.  Parity (fp32) mode never uses these.
+DEVINL void gelu_terms_fast(float x, float& cdf, float& pdf) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float e = __expf(-z * z);  // = exp(-x^2 / 2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * e;
+    const float erf_x = x < 0.f ? -erf_abs : erf_abs;
+    cdf = 0.5f * (1.0f + erf_x);
+    pdf = 0.39894228040143267794f * e;
+}
+DEVINL float act_fwd_fast(float x, int act) {
+    if (act == M3AE_ACT_GELU) {
+        float cdf, pdf;
+        gelu_terms_fast(x, cdf, pdf);
+        return x * cdf;
+    }
+    if (act == M3AE_ACT_QUICKGELU) return x * __frcp_rn(1.0f + __expf(-1.702f * x));
+    return act_fwd(x, act);
+}
+DEVINL float act_bwd_fast(float x, int act) {
+    if (act == M3AE_ACT_GELU) {
+        float cdf, pdf;
+        gelu_terms_fast(x, cdf, pdf);
+        return fmaf(x, pdf, cdf);
+    }
+    if (act == M3AE_ACT_QUICKGELU) {
+        const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+        return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    return act_bwd(x, act);
+}
+
 DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

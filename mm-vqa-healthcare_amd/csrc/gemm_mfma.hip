@@ -13,6 +13,7 @@
 // (the LDS-DMA destination is lane-linear) with the same involution on the read, so ds_read_b128 / tr reads are
 // bank-conflict free.  Workgroup ids are remapped so that each XCD (own L2) walks a contiguous range of tiles.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -21,9 +22,12 @@ __device__ __attribute__((aligned(256))) uint32_t g_m3ae_zero_page[64];  // 256 
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 64 KiB
+constexpr int BM = 128, BN = 128, BK = 64;         // TN kernel tile
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;    // 32 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 64 KiB
+
+// epilogue classes (template parameter: keeps erf/exp code out of the kernels that do not need it)
+enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_QGELU = 2, EPI_DGELU = 3, EPI_DQGELU = 4, EPI_ANY = 5 };
 
 struct MfmaArgs {
     const bf16_t* A; int64_t lda;
@@ -62,11 +66,12 @@ DEVINL void glds16(const void* src, char* lds_dst_uniform) {
 // 16 slots of the 256-B bank row.
 DEVINL int nt_swz(int row) { return (row >> 1) & 7; }
 
+template <int SEGS_PER_WAVE, int NWAVES>
 DEVINL void nt_stage(const bf16_t* G, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile, int wave,
                      int lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int seg = q * 4 + wave;  // 1 KiB = 8 rows per wave-instruction
+    for (int q = 0; q < SEGS_PER_WAVE; ++q) {
+        const int seg = q * NWAVES + wave;  // 1 KiB = 8 rows per wave-instruction
         const int row = seg * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ nt_swz(row);
         int64_t grow = row0 + row;
@@ -97,7 +102,7 @@ template <> struct Vec4<bf16_t> {
 };
 
 // Fused epilogue on 4 consecutive n of row m (8-byte bf16 / 16-byte fp32 accesses).
-template <typename TC>
+template <typename TC, int EPI>
 DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
     const int64_t off = m * a.ldc + n;
     float x[4] = {v[0] * a.alpha, v[1] * a.alpha, v[2] * a.alpha, v[3] * a.alpha};
@@ -107,20 +112,24 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] += y[t];
     }
-    if (a.preact) Vec4<TC>::st((TC*)a.preact + off, x);
-    if (a.act != M3AE_ACT_NONE) {
+    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
+        if (a.preact) Vec4<TC>::st((TC*)a.preact + off, x);
+        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = act_fwd(x[t], a.act);
+        for (int t = 0; t < 4; ++t) x[t] = act_fwd_fast(x[t], act);
     }
     if (a.residual) {
         Vec4<TC>::ld((const TC*)a.residual + off, y);
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] += y[t];
     }
-    if (a.dact_aux) {
-        Vec4<TC>::ld((const TC*)a.dact_aux + off, y);
+    if (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_ANY) {
+        if (a.dact_aux) {
+            const int dact = EPI == EPI_DGELU ? M3AE_ACT_GELU : (EPI == EPI_DQGELU ? M3AE_ACT_QUICKGELU : a.dact);
+            Vec4<TC>::ld((const TC*)a.dact_aux + off, y);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] *= act_bwd(y[t], a.dact);
+            for (int t = 0; t < 4; ++t) x[t] *= act_bwd_fast(y[t], dact);
+        }
     }
     if (a.accumulate) {
         Vec4<TC>::ld((const TC*)a.C + off, y);
@@ -130,17 +139,25 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
     Vec4<TC>::st((TC*)a.C + off, x);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
+// BM_ x BN_ output tile, one 64x64 sub-tile per wave ((BM_/64) x (BN_/64) waves), NST-stage LDS ring with the DMA
+// of stage t + NST - 1 issued before the MFMAs of stage t and retired by a COUNTED s_waitcnt (loads stay in flight
+// across the raw s_barrier).
+template <int BM_, int BN_, int NST, int EPI>
+__global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
+    constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / 64) * WAVES_N;
+    constexpr int A_BYTES = BM_ * BK * 2, ST_BYTES = (BM_ + BN_) * BK * 2;
+    constexpr int A_SEGS = BM_ / 8 / NWAVES, B_SEGS = BN_ / 8 / NWAVES;  // 1-KiB DMA pieces per wave per stage
+    constexpr int G = A_SEGS + B_SEGS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
-    const unsigned tiles_n = (unsigned)((a.N + BN - 1) / BN);
+    const unsigned tiles_n = (unsigned)((a.N + BN_ - 1) / BN_);
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(wg / tiles_n) * BM;
-    const int64_t n0 = (int64_t)(wg % tiles_n) * BN;
+    const int64_t m0 = (int64_t)(wg / tiles_n) * BM_;
+    const int64_t n0 = (int64_t)(wg % tiles_n) * BN_;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -149,21 +166,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = (int)(a.K / BK);
-    nt_stage(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-    nt_stage(a.B, a.ldb, n0, a.N, 0, smem + BM * BK * 2, wave, lane);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        if (s < nt) {
+            nt_stage<A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)s * BK, smem + s * ST_BYTES, wave, lane);
+            nt_stage<B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)s * BK, smem + s * ST_BYTES + A_BYTES, wave, lane);
+        }
+    }
 
     const int frow = lane & 15, fchunk = lane >> 4;
+    int cur_s = 0, nxt_s = NST - 1;
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile t has landed for every wave; everyone is done reading the other stage
-        char* cur = smem + (t & 1) * STAGE_BYTES;
-        if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-            nt_stage(a.A, a.lda, m0, a.M, (int64_t)(t + 1) * BK, nxt, wave, lane);
-            nt_stage(a.B, a.ldb, n0, a.N, (int64_t)(t + 1) * BK, nxt + BM * BK * 2, wave, lane);
+        // stage t has landed once at most the NST - 2 younger stages of this wave are still in flight
+        if (t + NST - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of stage t landed; everyone left stage t - 1's buffer
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) {
+            char* nxt = smem + nxt_s * ST_BYTES;
+            nt_stage<A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)(t + NST - 1) * BK, nxt, wave, lane);
+            nt_stage<B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)(t + NST - 1) * BK, nxt + A_BYTES, wave, lane);
         }
-        const char* At = cur;
-        const char* Bt = cur + BM * BK * 2;
+        const char* At = smem + cur_s * ST_BYTES;
+        const char* Bt = At + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             s16x8 af[4], bfr[4];
@@ -179,6 +204,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
         }
+        asm volatile("" ::: "memory");
+        cur_s = cur_s + 1 == NST ? 0 : cur_s + 1;
+        nxt_s = nxt_s + 1 == NST ? 0 : nxt_s + 1;
     }
 
     // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4 * (lane >> 4) + 0..3]
@@ -190,8 +218,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int64_t n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= a.N) continue;  // N % 4 == 0 is a precondition, so n < N implies n + 3 < N
-            if (a.c_f32) epilogue4<float>(a, m, n, acc[i][j]);
-            else epilogue4<bf16_t>(a, m, n, acc[i][j]);
+            if (a.c_f32) epilogue4<float, EPI>(a, m, n, acc[i][j]);
+            else epilogue4<bf16_t, EPI>(a, m, n, acc[i][j]);
         }
     }
 }
@@ -319,6 +347,33 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : 0;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
+extern "C" int m3ae_set_tuning(int key, int value) {
+    if (key == 0) { g_nt_variant = value; return 0; }
+    return M3AE_ERR_ARG;
+}
+
+template <int BM_, int BN_, int NST, int EPI>
+static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
+    constexpr int lds = NST * (BM_ + BN_) * BK * 2;
+    constexpr int threads = (BM_ / 64) * (BN_ / 64) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM_, BN_, NST, EPI>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM_, BN_, NST, EPI>), dim3((unsigned)tiles), dim3(threads), lds, s, a);
+    return hip_launch_status();
+}
+
+template <int EPI>
+static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
+    if (g_nt_variant == 1 && a.M > 128) return launch_nt_t<256, 128, 3, EPI>(a, s);
+    return launch_nt_t<128, 128, 2, EPI>(a, s);
+}
+
 static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     MfmaArgs a{};
     a.A = (const bf16_t*)d.A; a.lda = d.a_sm;
@@ -328,15 +383,13 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.c_f32 = d.dtype_c == M3AE_F32;
     a.alpha = d.alpha; a.accumulate = d.accumulate; a.bias = d.bias; a.act = d.act; a.preact = d.preact;
     a.residual = d.residual; a.dact_aux = d.dact_aux; a.dact = d.dact;
-    const int64_t tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((unsigned)tiles), dim3(256), LDS_BYTES, s, a);
-    return hip_launch_status();
+    const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
+    if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
+    if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);
+    if (!has_dact && d.act == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_QGELU>(a, s);
+    if (!has_act && d.dact == M3AE_ACT_GELU) return launch_nt_v<EPI_DGELU>(a, s);
+    if (!has_act && d.dact == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_DQGELU>(a, s);
+    return launch_nt_v<EPI_ANY>(a, s);
 }
 
 static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
@@ -359,7 +412,6 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.splits = (int)splits;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }

@@ -22,17 +22,54 @@ inline unsigned ew_grid(int64_t n) {
 }
 
 // ---- column sum ------------------------------------------------------------------------------------------
-// grid (cdiv(N, 256), row_chunks); each thread owns one column for its row chunk, one fp32 atomic per column.
-template <typename T>
-__global__ void colsum_kernel(const T* x, float* out, int64_t M, int64_t N, int64_t ldx, int64_t rows_per) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// workgroup = 32 column-groups (8 columns = 16 B bf16 / 2 x 16 B fp32 per lane per row) x 8 row-lanes; grid
+// (cdiv(N, 256), row_chunks); LDS-combine the row-lanes, one fp32 atomic per column per workgroup.
+template <typename T> DEVINL void ld8(const T* p, float* x);
+template <> DEVINL void ld8<float>(const float* p, float* x) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+}
+template <> DEVINL void ld8<bf16_t>(const bf16_t* p, float* x) {
+    const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { x[2 * t] = __uint_as_float(v[t] << 16); x[2 * t + 1] = __uint_as_float(v[t] & 0xffff0000u); }
+}
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int64_t M, int64_t N, int64_t ldx,
+                                                     int64_t rows_per) {
+    __shared__ float red[8][32][9];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * 256 + cg * 8;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per;
     int64_t r1 = r0 + rows_per;
     if (r1 > M) r1 = M;
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) acc += Elem<T>::ld(x + r * ldx + n);
-    atomicAdd(out + n, acc);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n0 < N) {
+        for (int64_t r = r0 + rl; r < r1; r += 8) {
+            if (VEC) {
+                float v[8];
+                ld8<T>(x + r * ldx + n0, v);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] += v[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (n0 + t < N) acc[t] += Elem<T>::ld(x + r * ldx + n0 + t);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[rl][cg][t] = acc[t];
+    __syncthreads();
+    if (rl == 0 && n0 < N) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r][cg][t];
+            if (n0 + t < N) atomicAdd(out + n0 + t, s);
+        }
+    }
 }
 
 // ---- RoBERTa embeddings ------------------------------------------------------------------------------------
@@ -277,12 +314,16 @@ extern "C" int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int6
         hipError_t e = hipMemsetAsync(out, 0, N * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    int64_t chunks = cdiv(M, 256);
-    if (chunks > 256) chunks = 256;
+    const int64_t col_blocks = cdiv(N, 256);
+    int64_t chunks = cdiv(1024, col_blocks);  // ~1024 workgroups in flight
+    if (chunks > cdiv(M, 64)) chunks = cdiv(M, 64);
+    if (chunks < 1) chunks = 1;
     const int64_t rows_per = cdiv(M, chunks);
     chunks = cdiv(M, rows_per);
-    dim3 grid((unsigned)cdiv(N, 256), (unsigned)chunks);
-    DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, out, M, N, ldx, rows_per));
+    dim3 grid((unsigned)col_blocks, (unsigned)chunks);
+    const bool vec = (N % 8 == 0) && (ldx % 8 == 0) && ((((uintptr_t)x) & 15) == 0);
+    if (vec) { DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_kernel<T, true>), grid, dim3(256), 0, s, (const T*)x, out, M, N, ldx, rows_per)); }
+    else { DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_kernel<T, false>), grid, dim3(256), 0, s, (const T*)x, out, M, N, ldx, rows_per)); }
     return hip_launch_status();
 }
 

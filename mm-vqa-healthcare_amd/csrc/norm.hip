@@ -163,14 +163,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblk, int D) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * D) return;
-    const int which = i / D, col = i - which * D;
+// fold the per-workgroup partial rows into the fp32 gradients: 32 columns x 8 row-lanes per workgroup
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblk,
+                                                            int D) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;  // index into [2][D]
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * 2 + which) * D + col];
-    if (which == 0) dgamma[col] += s;
-    else if (dbeta) dbeta[col] += s;
+    if (i < 2 * D) {
+        const int which = i / D, col = i - which * D;
+        for (int b = rl; b < nblk; b += 8) s += part[((int64_t)b * 2 + which) * D + col];
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < 2 * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][cl];
+        const int which = i / D, col = i - which * D;
+        if (which == 0) dgamma[col] += t;
+        else if (dbeta) dbeta[col] += t;
+    }
 }
 
 template <typename T, int CPL>
@@ -216,14 +229,14 @@ extern "C" int m3ae_layernorm_fwd(const void* x, const float* gamma, const float
 
 extern "C" int64_t m3ae_layernorm_bwd_blocks(int64_t M) {
     int64_t n = cdiv(M, 4);
-    return n < 1024 ? n : 1024;
+    return n < 512 ? n : 512;
 }
 
 extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* workspace, int64_t M, int64_t D, int dtype, int act, int rms, void* stream) {
     if (!dy || !x || !gamma || !rstd || !dx || !dgamma || !workspace || M <= 0) return M3AE_ERR_ARG;
-    if (D % 4 != 0 || D > 4096) return M3AE_ERR_UNSUPPORTED;
+    if (D % 4 != 0 || D > 2048) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (int)m3ae_layernorm_bwd_blocks(M);
     int rc = M3AE_ERR_UNSUPPORTED;
@@ -236,7 +249,7 @@ extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* ga
     };
     rc = run();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 256)), dim3(256), 0, s, workspace, dgamma,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 32)), dim3(256), 0, s, workspace, dgamma,
                        dbeta, nblk, (int)D);
     return hip_launch_status();
 }

@@ -63,6 +63,7 @@ _SIGS = {
     "m3ae_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
     "m3ae_scatter_add_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
     "m3ae_selftest": (C.c_int, [vp, vp]),
+    "m3ae_set_tuning": (C.c_int, [C.c_int, C.c_int]),
 }
 
 EXPORTS = tuple(_SIGS)

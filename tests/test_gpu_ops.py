@@ -52,15 +52,20 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
         assert ops.last_gemm_path() == expect
 
 
-def test_gemm_mfma_matches_generic_bitwise_shape_sweep():
-    """The MFMA NT kernel against the generic kernel on identical bf16 inputs, ragged M / N tails."""
-    for M, N, K in [(1, 128, 64), (127, 132, 192), (129, 260, 64), (300, 8, 3072), (1000, 3072, 768)]:
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
+    """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
+    from m3ae_amd import _lib
+    _lib.lib().m3ae_set_tuning(0, variant)
+    for M, N, K in [(1, 128, 64), (127, 132, 192), (129, 260, 64), (300, 8, 3072), (1000, 3072, 768), (577, 768, 128),
+                    (2308, 2304, 768)]:
         x, w = rnd(M, K, dtype=torch.bfloat16, seed=5), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=6)
         y1, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32)
         assert ops.last_gemm_path() == "mfma_nt"
         y2, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32, force_generic=True)
         assert ops.last_gemm_path() == "generic"
         close(y1, y2, 1e-5, 1e-5, msg=f"{M}x{N}x{K}")
+    _lib.lib().m3ae_set_tuning(0, 0)
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (577 * 2, 768, 768), (1000, 2304, 768), (4616, 768, 3072), (37, 128, 256)])

@@ -1,0 +1,56 @@
+"""Per-shape timing of the MFMA GEMM kernels (HIP events, interleaved variants in ONE process; random bf16 data)."""
+import os
+import sys
+import ctypes as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mm-vqa-healthcare_amd"))
+import torch  # noqa: E402
+from m3ae_amd import _lib, ops  # noqa: E402
+
+B = int(os.environ.get("B", 64))
+M = B * 577
+NT_SHAPES = [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768),
+             (4096, 4096, 4096), (8192, 8192, 8192)]
+TN_SHAPES = [(M, 768, 768), (M, 2304, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768)]
+
+
+def time_it(fn, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    L = _lib.lib()
+    dev = "cuda"
+    print(f"B={B}")
+    for (m, n, k) in NT_SHAPES:
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
+        y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        res = []
+        for rnd in range(2):
+            for v in (0, 1):
+                L.m3ae_set_tuning(0, v)
+                ms = time_it(lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k))
+                res.append((v, ms))
+        best = {v: min(ms for vv, ms in res if vv == v) for v in (0, 1)}
+        print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in (0, 1)), flush=True)
+    L.m3ae_set_tuning(0, 1)
+    for (m, n, k) in TN_SHAPES:
+        dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        g = torch.zeros(n, k, device=dev)
+        ms = time_it(lambda: ops.gemm(dy, 1, n, x, k, 1, g, k, n, k, m, accumulate=True))
+        print(f"TN red={m:6d} out {n:5d}x{k:5d}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
