@@ -43,6 +43,7 @@ struct MfmaArgs {
     const void* residual;
     const void* dact_aux;
     int dact;
+    int rows_epi;     // NT only: LDS-transposed row-contiguous epilogue (N % 8 == 0)
     int splits;       // TN only
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
 };
@@ -139,6 +140,91 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
     Vec4<TC>::st((TC*)a.C + off, x);
 }
 
+template <typename TC> struct Vec8;
+template <> struct Vec8<float> {
+    static DEVINL void ld(const float* p, float* x) { Vec4<float>::ld(p, x); Vec4<float>::ld(p + 4, x + 4); }
+    static DEVINL void st(float* p, const float* x) { Vec4<float>::st(p, x); Vec4<float>::st(p + 4, x + 4); }
+};
+template <> struct Vec8<bf16_t> {
+    static DEVINL void ld(const bf16_t* p, float* x) {
+        const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { x[2 * t] = __uint_as_float(v[t] << 16); x[2 * t + 1] = __uint_as_float(v[t] & 0xffff0000u); }
+    }
+    static DEVINL void st(bf16_t* p, const float* x) {
+        *(u32x4*)p = (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+    }
+};
+
+// Fused epilogue on 8 consecutive n of row m: 16-byte bf16 (2 x 16-byte fp32) accesses, 8 lanes = one 128-B line.
+template <typename TC, int EPI>
+DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x) {
+    const int64_t off = m * a.ldc + n;
+    float y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] *= a.alpha;
+    if (a.bias) {
+        Vec8<float>::ld(a.bias + n, y);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += y[t];
+    }
+    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
+        if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
+        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = act_fwd_fast(x[t], act);
+    }
+    if (a.residual) {
+        Vec8<TC>::ld((const TC*)a.residual + off, y);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += y[t];
+    }
+    if (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_ANY) {
+        if (a.dact_aux) {
+            const int dact = EPI == EPI_DGELU ? M3AE_ACT_GELU : (EPI == EPI_DQGELU ? M3AE_ACT_QUICKGELU : a.dact);
+            Vec8<TC>::ld((const TC*)a.dact_aux + off, y);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] *= act_bwd_fast(y[t], dact);
+        }
+    }
+    if (a.accumulate) {
+        Vec8<TC>::ld((const TC*)a.C + off, y);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] += y[t];
+    }
+    Vec8<TC>::st((TC*)a.C + off, x);
+}
+
+// Row-contiguous epilogue: the wave's 64x64 fp32 accumulator tile goes through its private LDS slab (two 32-row
+// halves, 68-float rows: conflict-free ds_write_b128 / ds_read_b128) so that every global access of the epilogue
+// is 8 lanes x 16 B = one whole 128-B line per row (the direct fragment layout touches 16 lines per instruction,
+// 32 B each, and made the N = 3072 GELU GEMMs store-issue bound).
+template <typename TC, int EPI>
+DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int64_t m_base, int64_t n_base,
+                          f32x4 (&acc)[4][4]) {
+    constexpr int LDW = 68;
+    float* t = (float*)smem + wave * 32 * LDW;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4*)(t + (16 * ii + (lane & 15)) * LDW + 16 * j + 4 * (lane >> 4)) = acc[2 * half + ii][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
+            const f32x4 v0 = *(const f32x4*)(t + row * LDW + col);
+            const f32x4 v1 = *(const f32x4*)(t + row * LDW + col + 4);
+            float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int64_t m = m_base + 32 * half + row, n = n_base + col;
+            if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // BM_ x BN_ output tile, one 64x64 sub-tile per wave ((BM_/64) x (BN_/64) waves), NST-stage LDS ring with the DMA
 // of stage t + NST - 1 issued before the MFMAs of stage t and retired by a COUNTED s_waitcnt (loads stay in flight
 // across the raw s_barrier).
@@ -209,7 +295,14 @@ __global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
         nxt_s = nxt_s + 1 == NST ? 0 : nxt_s + 1;
     }
 
-    // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4 * (lane >> 4) + 0..3]
+    if (a.rows_epi) {
+        __builtin_amdgcn_s_barrier();  // every wave has consumed its last stage: the ring is free for the C slabs
+        asm volatile("" ::: "memory");
+        if (a.c_f32) epilogue_rows<float, EPI>(a, smem, wave, lane, m0 + wr * 64, n0 + wc * 64, acc);
+        else epilogue_rows<bf16_t, EPI>(a, smem, wave, lane, m0 + wr * 64, n0 + wc * 64, acc);
+        return;
+    }
+    // direct epilogue (N % 8 != 0): lane holds C[m = .. + (lane & 15)][n = .. + 4 * (lane >> 4) + 0..3]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -383,6 +476,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.c_f32 = d.dtype_c == M3AE_F32;
     a.alpha = d.alpha; a.accumulate = d.accumulate; a.bias = d.bias; a.act = d.act; a.preact = d.preact;
     a.residual = d.residual; a.dact_aux = d.dact_aux; a.dact = d.dact;
+    a.rows_epi = (d.N % 8 == 0 && d.c_sm % 8 == 0) ? 1 : 0;
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
     if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);

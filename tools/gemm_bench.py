@@ -43,7 +43,24 @@ def main():
                 res.append((v, ms))
         best = {v: min(ms for vv, ms in res if vv == v) for v in (0, 1)}
         print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in (0, 1)), flush=True)
-    L.m3ae_set_tuning(0, 1)
+    L.m3ae_set_tuning(0, 0)
+    # epilogue-heavy forms on the dominant shapes (variant 0)
+    m = M
+    for (n, k, kind) in [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (768, 768, "bias+res"), (768, 3072, "bias+res")]:
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
+        y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(n, device=dev)
+        aux = torch.randn(m, n, device=dev).to(torch.bfloat16)
+        pre = torch.empty_like(y)
+        if kind == "gelu+preact":
+            fn = lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k, bias=b, act=ops.ACT_GELU, preact=pre)
+        elif kind == "dgelu":
+            fn = lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k, dact_aux=aux, dact=ops.ACT_GELU)
+        else:
+            fn = lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k, bias=b, residual=aux)
+        ms = time_it(fn)
+        print(f"NT {m:6d}x{n:5d}x{k:5d} {kind:12s}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
     for (m, n, k) in TN_SHAPES:
         dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
