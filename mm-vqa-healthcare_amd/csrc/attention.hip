@@ -75,12 +75,38 @@ DEVINL Stage4 tile_load(const bf16_t* base, int64_t sl, int64_t row0, int64_t nr
     }
     return s;
 }
+// Fast forms for FULL tiles: wave-uniform tile base (SGPR pair) + per-lane 32-bit element offsets computed once,
+// so the streaming loads cost no per-iteration vector address arithmetic.
+struct TileOffs { int t[4]; int rf; };
+DEVINL TileOffs make_offs(int lane, int64_t sl) {
+    TileOffs o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        o.t[i] = (c >> 3) * (int)sl + (c & 7) * 8;
+    }
+    o.rf = (lane & 31) * (int)sl + 8 * (lane >> 5);
+    return o;
+}
+DEVINL Stage4 tile_load_u(const bf16_t* tbase, const TileOffs& o) {
+    Stage4 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.v[i] = *(const s16x8*)(tbase + o.t[i]);
+    return s;
+}
+DEVINL s16x8 row_frag_u(const bf16_t* tbase, const TileOffs& o, int ks) { return *(const s16x8*)(tbase + o.rf + 16 * ks); }
+
 DEVINL void tile_store(char* tile, const Stage4& s, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = i * 64 + lane;
         *(s16x8*)(tile + (c >> 3) * VRS + (c & 7) * 16) = s.v[i];
     }
+}
+
+// Row-major A/B-operand fragment of tile row r from the same LDS image (16-byte read)
+DEVINL s16x8 lds_row_frag(const char* tile, int r, int ks, int h) {
+    return *(const s16x8*)(tile + r * VRS + 32 * ks + 16 * h);
 }
 
 // Transposed A-operand fragment from a [32 rows][64 d] LDS tile: MFMA row index = d = 32 * dt + (lane & 31),
@@ -110,6 +136,9 @@ DEVINL void store_rows(bf16_t* rowp, const f32x16& t0, const f32x16& t1, float m
     }
 }
 
+// raw v_exp_f32 (2^x): arguments here are <= 0 up to rounding, denormal results may flush -- no range fix-up code
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 DEVINL f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -120,7 +149,58 @@ DEVINL f32x16 zero16() {
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+// Flags are template parameters so that the hot instance (image keys: no mask, no bias, not causal) has a
+// branch-free loop body; only the LAST key tile pays for bounds handling.
+struct Flags { bool mask, bias, causal; };
+
+template <bool MASK, bool BIAS, bool CAUSAL, bool LAST>
+DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1, const AttnArgs& a, const float* mrow,
+                          const float* brow, int64_t key0, int64_t qi, int h) {
+    // log2-domain scores, additive mask / bias, bounds; online softmax update of (m, l, o)
+    constexpr bool PLAIN = !MASK && !BIAS && !CAUSAL && !LAST;  // hot path: scale folded into the exp argument
+    float tmax = -1e30f;
+    if (PLAIN) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tmax = fmaxf(tmax, s[reg]);
+        tmax *= a.scale_log2;
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t key = key0 + crow(reg, h);
+            float x = s[reg] * a.scale_log2;
+            if (MASK || BIAS) {
+                const int64_t kc = (LAST && key >= a.Lk) ? a.Lk - 1 : key;
+                if (MASK) x = fmaf(mrow[kc], LOG2E, x);
+                if (BIAS) x = fmaf(brow[kc], LOG2E, x);
+            }
+            if (LAST) x = key < a.Lk ? x : -INFINITY;
+            if (CAUSAL) x = key > qi ? -INFINITY : x;
+            s[reg] = x;
+            tmax = fmaxf(tmax, x);
+        }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__any(tmax > m)) {  // wave-uniform: the running max rarely moves after the first tiles
+        const float mnew = fmaxf(m, tmax);
+        const float alpha = fast_exp2(m - mnew);
+        m = mnew;
+        l *= alpha;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { o0[reg] *= alpha; o1[reg] *= alpha; }
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float p = PLAIN ? fast_exp2(fmaf(s[reg], a.scale_log2, -m)) : fast_exp2(s[reg] - m);
+        s[reg] = p;
+        lsum += p;
+    }
+    l += lsum;
+}
+
+template <int NQ, bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs a) {
+    // wave = NQ x 32 query rows; streams 32-key tiles
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -128,26 +208,32 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
     const int head = blockIdx.y;
     const int64_t b = blockIdx.z;
-    const int64_t q0 = qt * 32;
+    const int64_t q0 = qt * (32 * NQ);
     if (q0 >= a.Lq) return;  // whole wave; no barriers in this kernel
     char* tile = lds + wave * TILE_LDS;
 
-    const int64_t qi = q0 + r;
-    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
-    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
-    s16x8 qf[4];
+    int64_t qi[NQ];
+    s16x8 qf[NQ][4];
+    const float* brow[NQ];
+    f32x16 o[NQ][2];
+    float m[NQ], l[NQ];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_frag(qp, ks, h);
-
+    for (int n = 0; n < NQ; ++n) {
+        qi[n] = q0 + 32 * n + r;
+        const int64_t qrow = qi[n] < a.Lq ? qi[n] : a.Lq - 1;
+        const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[n][ks] = row_frag(qp, ks, h);
+        brow[n] = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+        o[n][0] = zero16(); o[n][1] = zero16();
+        m[n] = -1e30f; l[n] = 0.f;
+    }
     const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
     const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
-    const float* mrow = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
-    const float* brow = a.pos_bias ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
-
-    f32x16 o0 = zero16(), o1 = zero16();
-    float m = -1e30f, l = 0.f;
+    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
     const int nkt = (int)((a.Lk + 31) / 32);
 
+    const TileOffs ko = make_offs(lane, a.k_sl), vo = make_offs(lane, a.v_sl);
     s16x8 kf_n[4];
     {
         const int64_t kr = r < a.Lk ? r : a.Lk - 1;
@@ -162,57 +248,56 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
         for (int ks = 0; ks < 4; ++ks) kf[ks] = kf_n[ks];
         asm volatile("" ::: "memory");
         tile_store(tile, vs_n, lane);
-        if (kt + 1 < nkt) {
-            int64_t kr = (int64_t)(kt + 1) * 32 + r;
-            kr = kr < a.Lk ? kr : a.Lk - 1;
+        const bool last = kt + 1 == nkt;
+        if (!last) {
+            const int64_t row0 = (int64_t)(kt + 1) * 32;
+            if (row0 + 32 <= a.Lk) {  // full tile: uniform base + lane offsets
+                const bf16_t* kt_base = kbase + row0 * a.k_sl;
+                const bf16_t* vt_base = vbase + row0 * a.v_sl;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-            vs_n = tile_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, lane);
+                for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag_u(kt_base, ko, ks);
+                vs_n = tile_load_u(vt_base, vo);
+            } else {
+                int64_t kr = row0 + r;
+                kr = kr < a.Lk ? kr : a.Lk - 1;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+                vs_n = tile_load(vbase, a.v_sl, row0, a.Lk, lane);
+            }
         }
-        // S^T[key][q] = K . Q^T
-        f32x16 s = zero16();
+        f32x16 s[NQ];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);
-        // scale, additive mask / bias, bounds  (log2 domain)
-        float tmax = -1e30f;
+        for (int n = 0; n < NQ; ++n) {
+            s[n] = zero16();
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t key = (int64_t)kt * 32 + crow(reg, h);
-            float x = s[reg] * a.scale_log2;
-            const bool valid = key < a.Lk && !(a.causal && key > qi);
-            const int64_t kc = key < a.Lk ? key : a.Lk - 1;
-            if (mrow) x += mrow[kc] * LOG2E;
-            if (brow) x += brow[kc] * LOG2E;
-            x = valid ? x : -INFINITY;
-            s[reg] = x;
-            tmax = fmaxf(tmax, x);
+            for (int ks = 0; ks < 4; ++ks) s[n] = mfma32(kf[ks], qf[n][ks], s[n]);  // S^T[key][q] = K . Q^T
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mnew);
-        m = mnew;
-        float lsum = 0.f;
+        const int64_t key0 = (int64_t)kt * 32;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float p = exp2f(s[reg] - m);
-            s[reg] = p;
-            lsum += p;
+        for (int n = 0; n < NQ; ++n) {
+            if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
+            else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
         }
-        l = l * alpha + lsum;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) { o0[reg] *= alpha; o1[reg] *= alpha; }
-        const s16x8 pb0 = pack_acc(s, 0), pb1 = pack_acc(s, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's V tile is in LDS
         // O^T[d][q] += V^T[d][key] . P^T[key][q]
-        o0 = mfma32(tr_frag(tile, 0, 0, lane), pb0, o0);
-        o1 = mfma32(tr_frag(tile, 1, 0, lane), pb0, o1);
-        o0 = mfma32(tr_frag(tile, 0, 1, lane), pb1, o0);
-        o1 = mfma32(tr_frag(tile, 1, 1, lane), pb1, o1);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const s16x8 v0 = tr_frag(tile, 0, ss, lane), v1 = tr_frag(tile, 1, ss, lane);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const s16x8 pb = pack_acc(s[n], ss);
+                o[n][0] = mfma32(v0, pb, o[n][0]);
+                o[n][1] = mfma32(v1, pb, o[n][1]);
+            }
+        }
     }
-    const float ltot = l + __shfl_xor(l, 32, 64);
-    if (qi < a.Lq) {
-        store_rows(a.o + b * a.o_sb + qi * a.o_sl + head * 64, o0, o1, 1.0f / ltot, h);
-        if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi] = m + log2f(ltot);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float ltot = l[n] + __shfl_xor(l[n], 32, 64);
+        if (qi[n] < a.Lq) {
+            store_rows(a.o + b * a.o_sb + qi[n] * a.o_sl + head * 64, o[n][0], o[n][1], 1.0f / ltot, h);
+            if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi[n]] = m[n] + log2f(ltot);
+        }
     }
 }
 
@@ -238,7 +323,8 @@ __global__ void attn_delta_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // backward: dQ   (wave = 32 queries, streams key tiles)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+template <bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,24 +348,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 
     const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
     const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
-    const float* mrow = a.key_mask ? a.key_mask + b * a.Lk : nullptr;
-    const float* brow = a.pos_bias ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
-    float* dbrow = a.d_pos_bias ? a.d_pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
+    const float* brow = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+    float* dbrow = (BIAS && a.d_pos_bias) ? a.d_pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
 
     f32x16 g0 = zero16(), g1 = zero16();
     const int nkt = (int)((a.Lk + 31) / 32);
-    for (int kt = 0; kt < nkt; ++kt) {
-        int64_t kr = (int64_t)kt * 32 + r;
-        kr = kr < a.Lk ? kr : a.Lk - 1;
-        s16x8 kf[4], vf[4];
+    const TileOffs ko = make_offs(lane, a.k_sl), vo = make_offs(lane, a.v_sl);
+    s16x8 kf_n[4], vf_n[4];
+    {
+        const int64_t kr = r < a.Lk ? r : a.Lk - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-            vf[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
+            kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+            vf_n[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
         }
-        const Stage4 kst = tile_load(kbase, a.k_sl, (int64_t)kt * 32, a.Lk, lane);
+    }
+    Stage4 kst_n = tile_load(kbase, a.k_sl, 0, a.Lk, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        s16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kf_n[ks]; vf[ks] = vf_n[ks]; }
         asm volatile("" ::: "memory");
-        tile_store(tile, kst, lane);
+        tile_store(tile, kst_n, lane);
+        const bool last = kt + 1 == nkt;
+        if (!last) {
+            const int64_t row0 = (int64_t)(kt + 1) * 32;
+            if (row0 + 32 <= a.Lk) {
+                const bf16_t* kt_base = kbase + row0 * a.k_sl;
+                const bf16_t* vt_base = vbase + row0 * a.v_sl;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    kf_n[ks] = row_frag_u(kt_base, ko, ks);
+                    vf_n[ks] = row_frag_u(vt_base, vo, ks);
+                }
+                kst_n = tile_load_u(kt_base, ko);
+            } else {
+                int64_t kr = row0 + r;
+                kr = kr < a.Lk ? kr : a.Lk - 1;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
+                    vf_n[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
+                }
+                kst_n = tile_load(kbase, a.k_sl, row0, a.Lk, lane);
+            }
+        }
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
@@ -288,14 +402,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int64_t key = (int64_t)kt * 32 + crow(reg, h);
-            const bool valid = key < a.Lk && !(a.causal && key > qi);
-            const int64_t kc = key < a.Lk ? key : a.Lk - 1;
             float x = s[reg] * a.scale_log2;
-            if (mrow) x += mrow[kc] * LOG2E;
-            if (brow) x += brow[kc] * LOG2E;
-            const float p = valid ? exp2f(x - lse) : 0.f;
+            bool valid = true;
+            if (MASK || BIAS || last) {
+                const int64_t kc = key < a.Lk ? key : a.Lk - 1;
+                if (MASK) x = fmaf(mrow[kc], LOG2E, x);
+                if (BIAS) x = fmaf(brow[kc], LOG2E, x);
+                valid = key < a.Lk;
+            }
+            if (CAUSAL) valid = valid && key <= qi;
+            const float p = valid ? fast_exp2(x - lse) : 0.f;
             const float ds = p * (dp[reg] - dlt);
-            if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + kc, ds);
+            if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
             s[reg] = ds;
         }
         const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
@@ -312,7 +430,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // backward: dK, dV   (wave = 32 keys, streams query tiles)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
+template <bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[8 * TILE_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -332,30 +451,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
     s16x8 kfb[4], vfb[4];  // B operands: K^T[d][key], V^T[d][key]
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { kfb[ks] = row_frag(kp, ks, h); vfb[ks] = row_frag(vp, ks, h); }
-    const float mk = a.key_mask ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
+    const float mk = MASK ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
+    const bool key_ok = ki < a.Lk;
 
     const bf16_t* qbase = a.q + b * a.q_sb + head * 64;
     const bf16_t* dobase = a.d_o + b * a.o_sb + head * 64;
-    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;
+    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;    // 128-B aligned, padded to a multiple of 32
     const float* drow = a.delta + (b * a.H + head) * a.lse_stride;
-    const float* bcol = a.pos_bias ? a.pos_bias + (int64_t)head * a.Lq * a.Lk + krow : nullptr;
+    const float* bcol = BIAS ? a.pos_bias + (int64_t)head * a.Lq * a.Lk + krow : nullptr;
 
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
     const int nqt = (int)((a.Lq + 31) / 32);
+    const TileOffs qo = make_offs(lane, a.q_sl), doo = make_offs(lane, a.o_sl);
+    Stage4 qs_n = tile_load(qbase, a.q_sl, 0, a.Lq, lane);
+    Stage4 dos_n = tile_load(dobase, a.o_sl, 0, a.Lq, lane);
     for (int qt = 0; qt < nqt; ++qt) {
-        int64_t qr = (int64_t)qt * 32 + r;
-        qr = qr < a.Lq ? qr : a.Lq - 1;
-        s16x8 qfa[4], dofa[4];  // A operands: Q[q][d], dO[q][d]
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qfa[ks] = row_frag(qbase + qr * a.q_sl, ks, h);
-            dofa[ks] = row_frag(dobase + qr * a.o_sl, ks, h);
-        }
-        const Stage4 qs = tile_load(qbase, a.q_sl, (int64_t)qt * 32, a.Lq, lane);
-        const Stage4 dos = tile_load(dobase, a.o_sl, (int64_t)qt * 32, a.Lq, lane);
         asm volatile("" ::: "memory");
-        tile_store(qtile, qs, lane);
-        tile_store(dotile, dos, lane);
+        tile_store(qtile, qs_n, lane);
+        tile_store(dotile, dos_n, lane);
+        const bool last = qt + 1 == nqt;
+        if (!last) {
+            const int64_t row0 = (int64_t)(qt + 1) * 32;
+            if (row0 + 32 <= a.Lq) {
+                qs_n = tile_load_u(qbase + row0 * a.q_sl, qo);
+                dos_n = tile_load_u(dobase + row0 * a.o_sl, doo);
+            } else {
+                qs_n = tile_load(qbase, a.q_sl, row0, a.Lq, lane);
+                dos_n = tile_load(dobase, a.o_sl, row0, a.Lq, lane);
+            }
+        }
+        // per-row softmax statistics of this q tile: rows crow(reg, h) -> 4 aligned float4 groups
+        f32x4 lse4[4], dl4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            lse4[g4] = *(const f32x4*)(lrow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
+            dl4[g4] = *(const f32x4*)(drow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's Q / dO tiles are in LDS
+        s16x8 qfa[4], dofa[4];  // A operands: Q[q][d], dO[q][d] (row reads of the staged tiles)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qfa[ks] = lds_row_frag(qtile, r, ks, h); dofa[ks] = lds_row_frag(dotile, r, ks, h); }
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S[q][key]
@@ -365,17 +500,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
-            const int64_t qc = qq < a.Lq ? qq : a.Lq - 1;
-            const bool valid = qq < a.Lq && ki < a.Lk && !(a.causal && ki > qq);
-            float x = s[reg] * a.scale_log2 + mk;
-            if (bcol) x += bcol[qc * a.Lk] * LOG2E;
-            const float pv = valid ? exp2f(x - lrow[qc]) : 0.f;
+            bool valid = key_ok;
+            if (last) valid = valid && qq < a.Lq;
+            if (CAUSAL) valid = valid && ki <= qq;
+            float x = fmaf(s[reg], a.scale_log2, mk);
+            if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
+            const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
             p[reg] = pv;
-            s[reg] = pv * (dp[reg] - drow[qc]);
+            s[reg] = pv * (dp[reg] - dl4[reg >> 2][reg & 3]);
         }
         const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
         const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
         dv0 = mfma32(tr_frag(dotile, 0, 0, lane), p0, dv0);
         dv1 = mfma32(tr_frag(dotile, 1, 0, lane), p0, dv1);
@@ -386,11 +521,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
         dk0 = mfma32(tr_frag(qtile, 0, 1, lane), d1, dk0);
         dk1 = mfma32(tr_frag(qtile, 1, 1, lane), d1, dk1);
     }
-    if (ki < a.Lk) {
+    if (key_ok) {
         store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
         store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
     }
 }
+
+// flag dispatch (mask / bias / causal are wave-uniform launch properties)
+#define ATTN_DISPATCH3(KERNEL, grid, s, a, ...)                                                                       \
+    do {                                                                                                             \
+        const int f = (a.key_mask ? 1 : 0) | (a.pos_bias ? 2 : 0) | (a.causal ? 4 : 0);                              \
+        switch (f) {                                                                                                 \
+            case 0: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, false>), grid, dim3(256), 0, s, a); break;  \
+            case 1: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, false>), grid, dim3(256), 0, s, a); break;   \
+            case 2: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, false>), grid, dim3(256), 0, s, a); break;   \
+            case 3: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, false>), grid, dim3(256), 0, s, a); break;    \
+            case 4: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, true>), grid, dim3(256), 0, s, a); break;   \
+            case 5: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, true>), grid, dim3(256), 0, s, a); break;    \
+            case 6: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, true>), grid, dim3(256), 0, s, a); break;    \
+            default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, true>), grid, dim3(256), 0, s, a); break;    \
+        }                                                                                                            \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // fp32 reference-shaped path: row softmax kernels over the materialised score matrix
@@ -514,8 +665,13 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
         if (!bf16_layout_ok(d, false)) return M3AE_ERR_UNSUPPORTED;
         if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
-        dim3 grid((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, s, a);
+        if (d.Lq > 32 && d.Lk > 64) {  // 64 query rows per wave: K / V fragments are fetched once for two query blocks
+            dim3 grid((unsigned)cdiv(cdiv(d.Lq, 64), 4), (unsigned)d.H, (unsigned)d.B);
+            ATTN_DISPATCH3(attn_fwd_bf16_kernel, grid, s, a, 2, );
+        } else {
+            dim3 grid((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
+            ATTN_DISPATCH3(attn_fwd_bf16_kernel, grid, s, a, 1, );
+        }
         return hip_launch_status();
     }
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;
@@ -543,9 +699,9 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         const int64_t total = d.B * d.Lq * d.H;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, gq, dim3(256), 0, s, a);
+        ATTN_DISPATCH3(attn_bwd_dq_bf16_kernel, gq, s, a, );
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel, gk, dim3(256), 0, s, a);
+        ATTN_DISPATCH3(attn_bwd_dkdv_bf16_kernel, gk, s, a, );
         return hip_launch_status();
     }
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;

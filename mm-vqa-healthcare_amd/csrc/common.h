@@ -22,7 +22,12 @@ DEVINL bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
-DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two floats -> one dword of two bf16 (lo in bits 0..15): a single v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+DEVINL uint32_t pack2bf(float lo, float hi) {
+    const bf16x2_t v = __builtin_convertvector((f32x2){lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
