@@ -46,6 +46,8 @@ const char* m3ae_last_gemm_path(void);
  *           if (dact_aux) x *= act'(dact_aux[m][n]) (derivative of `dact` at the saved pre-activation);
  *           if (accumulate) C += x else C = x.
  * Strides are in ELEMENTS.  preact / residual / dact_aux share C's strides and dtype.
+ * a_rowsum (single-batch only): additionally accumulates the row sums of op(A) over the reduction -- for wgrad
+ * (A = dY^T) that is the bias gradient, so no separate column-sum pass over dY is needed.
  * Dispatch: bf16 A,B with K-contiguous operands (a_sk == b_sk == 1) -> MFMA "NT" kernel;
  *           bf16 A,B with reduction-strided operands (a_sm == b_sn == 1), fp32 C, accumulate -> MFMA "TN" (wgrad)
  *           kernel with split-K fp32 atomics; anything else (fp32 operands, odd shapes, batched) -> generic kernel.
@@ -66,6 +68,7 @@ typedef struct {
     const void* dact_aux;
     int32_t dact;
     int32_t force_generic; /* tests: bypass the MFMA kernels */
+    float* a_rowsum;       /* optional fp32 [M]: a_rowsum[m] += sum_k A[m][k] (bias gradient fused into wgrad) */
 } m3ae_gemm_desc;
 int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
 
@@ -107,15 +110,16 @@ int m3ae_attn_bwd(const m3ae_attn_desc* d, void* stream);
  * LayerNorm (biased variance, eps inside the sqrt, fp32 statistics), optional fused activation on the output.
  * Replaces nn.LayerNorm at bert_model.py:357,363,435,441 (eps 1e-12 / 1e-5), clip_model.py:27-33 (fp32 upcast),
  * m3ae_module.py:122 (+ nn.GELU :123 via `act`).  mean / rstd: fp32 [M] saved for backward.
- * bwd: dx = LN'(dy); dgamma / dbeta are ACCUMULATED (+=) in fp32.  workspace: fp32 [2 * nblk * D] with
+ * bwd: dx = LN'(dy) (+ dx_add: the residual branch's gradient of a pre-LN block, fused); dgamma / dbeta are
+ * ACCUMULATED (+=) in fp32 (dgamma may be NULL for frozen parameters).  workspace: fp32 [2 * nblk * D] with
  * nblk = m3ae_layernorm_bwd_blocks(M).  rms != 0 selects T5 RMSNorm (no mean subtraction, no beta).
  */
 int m3ae_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int64_t M, int64_t D, float eps, int dtype, int act, int rms, void* stream);
 int64_t m3ae_layernorm_bwd_blocks(int64_t M);
 int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
-                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t M,
-                       int64_t D, int dtype, int act, int rms, void* stream);
+                       const float* rstd, void* dx, const void* dx_add, float* dgamma, float* dbeta, float* workspace,
+                       int64_t M, int64_t D, int dtype, int act, int rms, void* stream);
 
 /* out[n] (+)= sum_m x[m][n]  (bias gradients; x has row stride ldx elements). */
 int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,

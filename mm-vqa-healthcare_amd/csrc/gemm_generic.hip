@@ -28,6 +28,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const bool do_rowsum = d.a_rowsum != nullptr && blockIdx.x == 0 && tx == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
     for (int64_t k0 = 0; k0 < d.K; k0 += TK) {
 #pragma unroll
@@ -62,8 +64,19 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rs[i] += a[i];
+            }
         }
         __syncthreads();
+    }
+    if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t gm = m0 + ty * 4 + i;
+            if (gm < d.M) d.a_rowsum[gm] += rs[i];  // one writer per row (blockIdx.x == 0, tx == 0)
+        }
     }
 
     TC* C = (TC*)d.C + coff;

@@ -43,6 +43,7 @@ struct MfmaArgs {
     const void* residual;
     const void* dact_aux;
     int dact;
+    float* a_rowsum;  // TN only: fp32 [N1] += column sums of A (bias gradient)
     int rows_epi;     // NT only: LDS-transposed row-contiguous epilogue (N % 8 == 0)
     int splits;       // TN only
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
@@ -380,6 +381,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient rides along: the waves of the first output-column tile also multiply their A^T fragments by a
+    // ones fragment (every column of that product is the row sum of A^T = the column sum of dY)
+    const bool do_rowsum = a.a_rowsum != nullptr && n0 == 0 && wc == 0;
+    f32x4 rsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
     tn_stage(a.A, a.lda, r_begin, r_end, m0, smem, wave, lane);
     tn_stage(a.B, a.ldb, r_begin, r_end, n0, smem + BM * BK * 2, wave, lane);
 
@@ -409,7 +418,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
                     // D[n1][n2] = sum_r A^T[n1][r] * B[r][n2]
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), rsum[i], 0, 0, 0);
+            }
         }
+    }
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(a.a_rowsum + m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r, rsum[i][r]);
     }
 
     // lane holds D[n1 = .. + 4 * (lane >> 4) + reg][n2 = .. + (lane & 15)]
@@ -493,7 +514,7 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.B = (const bf16_t*)d.B; a.ldb = d.b_sk;
     a.C = d.C; a.ldc = d.c_sm;
     a.M = d.M; a.N = d.N; a.K = d.K;
-    a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate;
+    a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
     const int64_t tiles = (d.M / BM) * (d.N / BN);
     const int64_t ksteps = cdiv(d.K, BK);
     int64_t splits = 768 / tiles;  // aim at ~3 workgroups per CU
@@ -525,7 +546,7 @@ extern "C" int m3ae_gemm(const m3ae_gemm_desc* dp, void* stream) {
                             (!d.preact || aligned16(d.preact)) && (!d.residual || aligned16(d.residual)) &&
                             (!d.dact_aux || aligned16(d.dact_aux)) && (!d.bias || aligned16(d.bias));
         // NT: both operands K-contiguous
-        if (ptr_ok && d.a_sk == 1 && d.b_sk == 1 && d.K % BK == 0 && d.N % 4 == 0 && d.a_sm % 8 == 0 &&
+        if (ptr_ok && !d.a_rowsum && d.a_sk == 1 && d.b_sk == 1 && d.K % BK == 0 && d.N % 4 == 0 && d.a_sm % 8 == 0 &&
             d.b_sn % 8 == 0 && d.c_sm % 4 == 0 && d.M >= 1) {
             g_last_path = "mfma_nt";
             return launch_nt(d, s);

@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("c_sm", i64), ("c_sn", i64), ("c_sb1", i64), ("c_sb2", i64),
         ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
         ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
-        ("dact_aux", vp), ("dact", i32), ("force_generic", i32),
+        ("dact_aux", vp), ("dact", i32), ("force_generic", i32), ("a_rowsum", vp),
     ]
 
 
@@ -45,7 +45,7 @@ _SIGS = {
     "m3ae_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
-    "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_colsum": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),

@@ -6,6 +6,8 @@ Pre-LN block = LayerNorm(fp32 stats) -> packed in-proj GEMM -> flash attention -
 Activations stay [B, L, D] (the reference's NLD->LND permutes at clip_model.py:102-104 are layout only).
 The tower runs `layers - 1` blocks (clip_model.py:71) -- the METER/M3AE quirk the checkpoints depend on.
 """
+from types import SimpleNamespace as NS
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -46,8 +48,18 @@ class ResidualAttentionBlock(nn.Module):
         self.mlp.add_module("gelu", QuickGELU())
         self.mlp.add_module("c_proj", nn.Linear(d_model * 4, d_model))
         self.ln_2 = LayerNorm(d_model)
+        self._bp = None
 
     def forward(self, x):
+        if self._bp is None:
+            a, m = self.attn, self.mlp
+            self._bp = NS(heads=a.num_heads, ln1=self.ln_1, ln2=self.ln_2, w_in=a.in_proj_weight, b_in=a.in_proj_bias,
+                          w_out=a.out_proj.weight, b_out=a.out_proj.bias, w_fc=m.c_fc.weight, b_fc=m.c_fc.bias,
+                          w_proj=m.c_proj.weight, b_proj=m.c_proj.bias)
+            self._anchors = tuple(self.parameters())
+        return ops.ClipBlockFn.apply(x, self._bp, *self._anchors)
+
+    def forward_unfused(self, x):
         h = ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         qkv = ops.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
         ctx = ops.self_attention(qkv, None, self.attn.num_heads)

@@ -65,7 +65,7 @@ def compute_weight(w):
 # ----------------------------------------------------------------------------------------------------------
 def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulate=False, bias=None, act=ACT_NONE,
          preact=None, residual=None, dact_aux=None, dact=ACT_NONE, force_generic=False, batch=(1, 1),
-         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0)):
+         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0), a_rowsum=None):
     _need_cuda(c)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -86,6 +86,9 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
             setattr(d, name, t.data_ptr())
     d.dact = dact
     d.force_generic = int(force_generic)
+    if a_rowsum is not None:
+        assert a_rowsum.dtype == torch.float32 and a_rowsum.numel() >= M and batch == (1, 1)
+        d.a_rowsum = a_rowsum.data_ptr()
     e0 = _prof_begin()
     check(_lib.lib().m3ae_gemm(C.byref(d), _stream()), "m3ae_gemm")
     if e0 is not None:
@@ -135,15 +138,22 @@ def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None):
     return dx
 
 
-def mm_wgrad(dy, x2, ldx, w_param):
-    """w.grad[N,K] += dy[M,N]^T . x2[M,K]  (fp32 accumulate in place)."""
+def mm_wgrad(dy, x2, ldx, w_param, b_param=None):
+    """w.grad[N,K] += dy[M,N]^T . x2[M,K]  (fp32 accumulate in place); with b_param also b.grad[N] += colsum(dy),
+    fused into the same kernel (row sums of the A operand dy^T)."""
+    want_b = b_param is not None and b_param.requires_grad
     if not w_param.requires_grad:
+        if want_b:
+            bias_grad(dy, b_param)
         return
     g = _grad_buf(w_param)
     M, N = dy.shape
     K = g.shape[1]
-    gemm(dy, 1, dy.stride(0), x2, ldx, 1, g, g.stride(0), N, K, M, accumulate=True)
+    gemm(dy, 1, dy.stride(0), x2, ldx, 1, g, g.stride(0), N, K, M, accumulate=True,
+         a_rowsum=_grad_buf(b_param) if want_b else None)
     _done(w_param)
+    if want_b:
+        _done(b_param)
 
 
 def bias_grad(dy, b_param):
@@ -216,9 +226,9 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(-1, N)
         dres = dy if ctx.has_res else None
         dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
-        mm_wgrad(dz, x2, ctx.ldx, ctx.weight)
         dextra = None
         if ctx.extra_needs:
+            mm_wgrad(dz, x2, ctx.ldx, ctx.weight)
             dextra = torch.empty(N, dtype=torch.float32, device=dz.device)
             check(_lib.lib().m3ae_colsum(_p(dz), _p(dextra), dz.shape[0], N, dz.stride(0), _dt(dz), 0, _stream()),
                   "m3ae_colsum")
@@ -226,7 +236,7 @@ class LinearFn(torch.autograd.Function):
                 _grad_buf(ctx.bias).add_(dextra)
                 _done(ctx.bias)
         else:
-            bias_grad(dz, ctx.bias)
+            mm_wgrad(dz, x2, ctx.ldx, ctx.weight, ctx.bias)
         dx = None
         if ctx.x_needs:
             dx = mm_dgrad(dz, ctx.weight).view(ctx.x_shape)
@@ -253,8 +263,7 @@ class GatherLinearFn(torch.autograd.Function):
         B, L, D = xc.shape
         dy2 = dy.contiguous()
         dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
-        mm_wgrad(dz, xc, L * D, ctx.weight)
-        bias_grad(dz, ctx.bias)
+        mm_wgrad(dz, xc, L * D, ctx.weight, ctx.bias)
         dx = torch.zeros_like(xc)
         wt = getattr(ctx.weight, "m3ae_t", None)
         N = dz.shape[1]
@@ -287,11 +296,9 @@ class MLPFn(torch.autograd.Function):
         w1, b1, w2, b2 = ctx.p
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
         dres = dy if ctx.has_res else None
-        mm_wgrad(dy2, g, g.stride(0), w2)
-        bias_grad(dy2, b2)
+        mm_wgrad(dy2, g, g.stride(0), w2, b2)
         du = mm_dgrad(dy2, w2, dact_aux=u, dact=ctx.act)  # dU = (dY W2) * act'(U)
-        mm_wgrad(du, x2, ctx.ldx, w1)
-        bias_grad(du, b1)
+        mm_wgrad(du, x2, ctx.ldx, w1, b1)
         dx = mm_dgrad(du, w1).view(ctx.x_shape)
         return dx, dres, None, None, None, None, None
 
@@ -337,8 +344,8 @@ class LayerNormFn(torch.autograd.Function):
         ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=xc.device)
         gg = _grad_buf(ctx.gamma)
         gb = _grad_buf(ctx.beta) if ctx.beta is not None else None
-        check(L.m3ae_layernorm_bwd(_p(dyc), _p(xc), _p(ctx.gamma), _p(ctx.beta), _p(mean), _p(rstd), _p(dx), _p(gg),
-                                   _p(gb), _p(ws), M, D, _dt(xc), ctx.act, int(ctx.rms), _stream()),
+        check(L.m3ae_layernorm_bwd(_p(dyc), _p(xc), _p(ctx.gamma), _p(ctx.beta), _p(mean), _p(rstd), _p(dx), None,
+                                   _p(gg), _p(gb), _p(ws), M, D, _dt(xc), ctx.act, int(ctx.rms), _stream()),
               "m3ae_layernorm_bwd")
         _done(ctx.gamma)
         _done(ctx.beta)
@@ -347,6 +354,37 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps, act=ACT_NONE, rms=False):
     return LayerNormFn.apply(x, gamma, beta, eps, act, rms)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# raw LayerNorm helpers (no autograd) for the fused block functions
+# ----------------------------------------------------------------------------------------------------------
+def ln_fwd_raw(x2, ln, act=ACT_NONE):
+    M, D = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(M, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2.device)
+    check(_lib.lib().m3ae_layernorm_fwd(_p(x2), _p(ln.weight), _p(ln.bias), _p(y), _p(mean), _p(rstd), M, D, ln.eps,
+                                        _dt(x2), act, 0, _stream()), "m3ae_layernorm_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE):
+    """dx = LN'(dy) (+ dx_add); ln.weight.grad / ln.bias.grad accumulate in place."""
+    M, D = x2.shape
+    L = _lib.lib()
+    dx = torch.empty_like(x2)
+    nblk = L.m3ae_layernorm_bwd_blocks(M)
+    ws = torch.empty(2 * nblk * D, dtype=torch.float32, device=x2.device)
+    train = ln.weight.requires_grad
+    gg = _grad_buf(ln.weight) if train else None
+    gb = _grad_buf(ln.bias) if (train and ln.bias is not None) else None
+    check(L.m3ae_layernorm_bwd(_p(dy), _p(x2), _p(ln.weight), _p(ln.bias), _p(mean), _p(rstd), _p(dx), _p(dx_add),
+                               _p(gg), _p(gb), _p(ws), M, D, _dt(x2), act, 0, _stream()), "m3ae_layernorm_bwd")
+    if train:
+        _done(ln.weight)
+        _done(ln.bias)
+    return dx
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -464,6 +502,185 @@ def self_attention(qkv, key_mask, heads):
 
 def cross_attention(q, kv, key_mask, heads):
     return CrossAttnFn.apply(q, kv, key_mask, heads)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fused transformer blocks: ONE autograd node per block, hand-written backward, every gradient join of the block
+# (residual branches) folded into a dgrad-GEMM or LayerNorm-backward epilogue -- no autograd add / copy kernels.
+# `P` is a plain namespace of parameter references built by the module (m3ae_amd/modules/*); `anchors` are the same
+# parameters as tensors so that autograd records the node.
+# ----------------------------------------------------------------------------------------------------------
+def _bdata(b):
+    return None if b is None else (b.data if hasattr(b, "members") else b.detach())
+
+
+def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P):
+    """BertAttention (bert_model.py:367-413) on 2-D token-major activations. Returns (y, saved)."""
+    heads = P.heads
+    D = h2.shape[1]
+    if other2 is None:
+        qkv, _ = mm_nt(h2, D, B * L, compute_weight(P.w_qkv), bias=_bdata(P.b_qkv))
+        v3 = qkv.view(B, L, 3 * D)
+        o, lse = attn_forward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], heads, mask)
+        proj = (qkv,)
+    else:
+        q, _ = mm_nt(h2, D, B * L, compute_weight(P.w_q), bias=_bdata(P.b_q))
+        kv, _ = mm_nt(other2, other2.shape[1], B * Lo, compute_weight(P.w_kv), bias=_bdata(P.b_kv))
+        kv3 = kv.view(B, Lo, 2 * D)
+        o, lse = attn_forward(q.view(B, L, D), kv3[..., :D], kv3[..., D:], heads, mask)
+        proj = (q, kv)
+    o2 = o.view(B * L, D)
+    s, _ = mm_nt(o2, D, B * L, compute_weight(P.w_o), bias=_bdata(P.b_o), residual=h2)
+    y, mean, rstd = ln_fwd_raw(s, P.ln)
+    return y, (h2, other2, proj, o, lse, s, mean, rstd, mask)
+
+
+def _attn_sub_bwd(dy, saved, B, L, Lo, P, need_dother=True):
+    h2, other2, proj, o, lse, s, mean, rstd, mask = saved
+    D = h2.shape[1]
+    ds = ln_bwd_raw(dy, s, P.ln, mean, rstd)
+    o2 = o.view(B * L, D)
+    mm_wgrad(ds, o2, D, P.w_o, P.b_o)
+    dctx = mm_dgrad(ds, P.w_o)
+    if other2 is None:
+        (qkv,) = proj
+        v3 = qkv.view(B, L, 3 * D)
+        dqkv = torch.empty_like(qkv)
+        d3 = dqkv.view(B, L, 3 * D)
+        attn_backward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], o, lse, dctx.view(B, L, D), d3[..., :D],
+                      d3[..., D:2 * D], d3[..., 2 * D:], P.heads, mask)
+        mm_wgrad(dqkv, h2, D, P.w_qkv, P.b_qkv)
+        dh = mm_dgrad(dqkv, P.w_qkv, residual=ds)  # + residual-branch gradient, fused
+        return dh, None
+    q, kv = proj
+    kv3 = kv.view(B, Lo, 2 * D)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    dkv3 = dkv.view(B, Lo, 2 * D)
+    attn_backward(q.view(B, L, D), kv3[..., :D], kv3[..., D:], o, lse, dctx.view(B, L, D), dq.view(B, L, D),
+                  dkv3[..., :D], dkv3[..., D:], P.heads, mask)
+    mm_wgrad(dq, h2, D, P.w_q, P.b_q)
+    mm_wgrad(dkv, other2, other2.shape[1], P.w_kv, P.b_kv)
+    dh = mm_dgrad(dq, P.w_q, residual=ds)
+    dother = mm_dgrad(dkv, P.w_kv) if need_dother else None
+    return dh, dother
+
+
+def _ffn_sub_fwd(h2, P):
+    """BertIntermediate + BertOutput (bert_model.py:416-442, 500-503)."""
+    M, D = h2.shape
+    g, u = mm_nt(h2, D, M, compute_weight(P.w1), bias=_bdata(P.b1), act=ACT_GELU, want_preact=True)
+    s, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), bias=_bdata(P.b2), residual=h2)
+    y, mean, rstd = ln_fwd_raw(s, P.ln)
+    return y, (h2, u, g, s, mean, rstd)
+
+
+def _ffn_sub_bwd(dy, saved, P):
+    h2, u, g, s, mean, rstd = saved
+    ds = ln_bwd_raw(dy, s, P.ln, mean, rstd)
+    mm_wgrad(ds, g, g.shape[1], P.w2, P.b2)
+    du = mm_dgrad(ds, P.w2, dact_aux=u, dact=ACT_GELU)
+    mm_wgrad(du, h2, h2.shape[1], P.w1, P.b1)
+    return mm_dgrad(du, P.w1, residual=ds)
+
+
+class BertCrossLayerFn(torch.autograd.Function):
+    """BertCrossLayer.forward (bert_model.py:457-498): self-attn -> cross-attn -> FFN as one node."""
+
+    @staticmethod
+    def forward(ctx, h, other, mask_self, mask_other, P, *anchors):
+        B, L, D = h.shape
+        Lo = other.shape[1]
+        h2 = h.contiguous().view(B * L, D)
+        other2 = other.contiguous().view(B * Lo, other.shape[2])
+        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask_self, P.attn)
+        c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross)
+        y, s3 = _ffn_sub_fwd(c, P.ffn)
+        ctx.saved = (s1, s2, s3)
+        ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, Lo, D), len(anchors)
+        ctx.need_other = other.requires_grad
+        return y.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, Lo, D = ctx.dims
+        s1, s2, s3 = ctx.saved
+        ctx.saved = None
+        P = ctx.P
+        dc = _ffn_sub_bwd(dy.contiguous().view(B * L, D), s3, P.ffn)
+        da, dother = _attn_sub_bwd(dc, s2, B, L, Lo, P.cross, need_dother=ctx.need_other)
+        dh, _ = _attn_sub_bwd(da, s1, B, L, L, P.attn)
+        return (dh.view(B, L, D), None if dother is None else dother.view(B, Lo, -1), None, None, None) + \
+               (None,) * ctx.n_anchor
+
+
+class BertSelfLayerFn(torch.autograd.Function):
+    """BertSelfLayer == HF RobertaLayer (bert_model.py:506-546; m3ae_module.py:233-234)."""
+
+    @staticmethod
+    def forward(ctx, h, mask, P, *anchors):
+        B, L, D = h.shape
+        h2 = h.contiguous().view(B * L, D)
+        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask, P.attn)
+        y, s3 = _ffn_sub_fwd(a, P.ffn)
+        ctx.saved = (s1, s3)
+        ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
+        return y.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, D = ctx.dims
+        s1, s3 = ctx.saved
+        ctx.saved = None
+        da = _ffn_sub_bwd(dy.contiguous().view(B * L, D), s3, ctx.P.ffn)
+        dh, _ = _attn_sub_bwd(da, s1, B, L, L, ctx.P.attn)
+        return (dh.view(B, L, D), None, None) + (None,) * ctx.n_anchor
+
+
+class ClipBlockFn(torch.autograd.Function):
+    """ResidualAttentionBlock.forward (clip_model.py:60-63), pre-LN: x += MHA(LN1(x)); x += MLP(LN2(x))."""
+
+    @staticmethod
+    def forward(ctx, x, P, *anchors):
+        B, L, D = x.shape
+        M = B * L
+        x2 = x.contiguous().view(M, D)
+        h1, m1, r1 = ln_fwd_raw(x2, P.ln1)
+        qkv, _ = mm_nt(h1, D, M, compute_weight(P.w_in), bias=_bdata(P.b_in))
+        v3 = qkv.view(B, L, 3 * D)
+        o, lse = attn_forward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], P.heads, None)
+        xa, _ = mm_nt(o.view(M, D), D, M, compute_weight(P.w_out), bias=_bdata(P.b_out), residual=x2)
+        h2, m2, r2 = ln_fwd_raw(xa, P.ln2)
+        g, u = mm_nt(h2, D, M, compute_weight(P.w_fc), bias=_bdata(P.b_fc), act=ACT_QUICKGELU, want_preact=True)
+        y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w_proj), bias=_bdata(P.b_proj), residual=xa)
+        ctx.saved = (x2, m1, r1, h1, qkv, o, lse, xa, m2, r2, h2, u, g)
+        ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
+        return y.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, D = ctx.dims
+        M = B * L
+        x2, m1, r1, h1, qkv, o, lse, xa, m2, r2, h2, u, g = ctx.saved
+        ctx.saved = None
+        P = ctx.P
+        dy2 = dy.contiguous().view(M, D)
+        mm_wgrad(dy2, g, g.shape[1], P.w_proj, P.b_proj)
+        du = mm_dgrad(dy2, P.w_proj, dact_aux=u, dact=ACT_QUICKGELU)
+        mm_wgrad(du, h2, D, P.w_fc, P.b_fc)
+        dh2 = mm_dgrad(du, P.w_fc)
+        dxa = ln_bwd_raw(dh2, xa, P.ln2, m2, r2, dx_add=dy2)  # + residual branch, fused into LN backward
+        mm_wgrad(dxa, o.view(M, D), D, P.w_out, P.b_out)
+        dctx = mm_dgrad(dxa, P.w_out)
+        v3 = qkv.view(B, L, 3 * D)
+        dqkv = torch.empty_like(qkv)
+        d3 = dqkv.view(B, L, 3 * D)
+        attn_backward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], o, lse, dctx.view(B, L, D), d3[..., :D],
+                      d3[..., D:2 * D], d3[..., 2 * D:], P.heads, None)
+        mm_wgrad(dqkv, h1, D, P.w_in, P.b_in)
+        dh1 = mm_dgrad(dqkv, P.w_in)
+        dx = ln_bwd_raw(dh1, x2, P.ln1, m1, r1, dx_add=dxa)
+        return (dx.view(B, L, D), None) + (None,) * ctx.n_anchor
 
 
 # ----------------------------------------------------------------------------------------------------------

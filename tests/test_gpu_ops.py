@@ -73,14 +73,18 @@ def test_gemm_wgrad_tn(M, N, K):
     """dW[N,K] += dY[M,N]^T X[M,K]: MFMA TN kernel (transposing LDS reads, split-K atomics), fp32 accumulate."""
     dy, x = rnd(M, N, dtype=torch.bfloat16, seed=7), rnd(M, K, dtype=torch.bfloat16, seed=8)
     g = torch.ones(N, K, dtype=torch.float32, device=dev())
-    ops.gemm(dy, 1, N, x, K, 1, g, K, N, K, M, accumulate=True)
+    db = torch.full((N,), 2.0, dtype=torch.float32, device=dev())
+    ops.gemm(dy, 1, N, x, K, 1, g, K, N, K, M, accumulate=True, a_rowsum=db)
     assert ops.last_gemm_path() == "mfma_tn"
     ref = 1.0 + dy.float().t() @ x.float()
     close(g, ref, 1e-4, 1e-3 * math.sqrt(M), msg="wgrad")
+    close(db, 2.0 + dy.float().sum(0), 1e-4, 1e-3 * math.sqrt(M), msg="fused bias grad")
     g32 = torch.zeros(N, K, dtype=torch.float32, device=dev())
-    ops.gemm(dy.float(), 1, N, x.float(), K, 1, g32, K, N, K, M, accumulate=True)
+    db32 = torch.zeros(N, dtype=torch.float32, device=dev())
+    ops.gemm(dy.float(), 1, N, x.float(), K, 1, g32, K, N, K, M, accumulate=True, a_rowsum=db32)
     assert ops.last_gemm_path() == "generic"
     close(g32, ref - 1.0, 1e-4, 1e-4 * math.sqrt(M), msg="wgrad fp32")
+    close(db32, dy.float().sum(0), 1e-4, 1e-4 * math.sqrt(M), msg="fused bias grad fp32")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
