@@ -63,27 +63,34 @@ DEVINL void glds16(const void* src, char* lds_dst_uniform) {
 // ---------------------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------------------
-// LDS image of an operand tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk c of row r stored at chunk
-// position c ^ ((r >> 1) & 7): a ds_read_b128 lane group (8 rows x one chunk + 8 rows x the next) then covers all
-// 16 slots of the 256-B bank row.
-DEVINL int nt_swz(int row) { return (row >> 1) & 7; }
+// LDS image of an operand tile: [rows][BKT k] bf16, 16-B chunk c of row r stored at chunk position c ^ swz(r), chosen
+// so that every ds_read_b128 lane group ({0-3,12-15,20-27}, ...: 8 rows x chunk c + 8 rows x chunk c^1) covers all 16
+// slots of the 256-B bank row:
+//   BKT = 64 (128-B rows, 2 rows per bank row): swz = (r >> 1) & 7
+//   BKT = 32 ( 64-B rows, 4 rows per bank row): swz = (4 - ((r >> 2) & 3)) & 3
+template <int BKT> DEVINL int nt_swz(int row) {
+    return BKT == 64 ? ((row >> 1) & 7) : ((4 - ((row >> 2) & 3)) & 3);
+}
 
-template <int SEGS_PER_WAVE, int NWAVES>
+// one 1-KiB LDS-DMA piece per wave-instruction = 1024 / (2 * BKT) rows
+template <int BKT, int SEGS_PER_WAVE, int NWAVES>
 DEVINL void nt_stage(const bf16_t* G, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile, int wave,
                      int lane) {
+    constexpr int CPR = BKT / 8;         // 16-B chunks per row
+    constexpr int RPS = 64 / CPR;        // rows per piece
 #pragma unroll
     for (int q = 0; q < SEGS_PER_WAVE; ++q) {
-        const int seg = q * NWAVES + wave;  // 1 KiB = 8 rows per wave-instruction
-        const int row = seg * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ nt_swz(row);
+        const int seg = q * NWAVES + wave;
+        const int row = seg * RPS + lane / CPR;
+        const int chunk = (lane % CPR) ^ nt_swz<BKT>(row);
         int64_t grow = row0 + row;
         grow = grow < nrows ? grow : nrows - 1;  // clamp: duplicated rows are computed but never stored
         glds16(G + grow * ld + k0 + chunk * 8, tile + seg * 1024);
     }
 }
 
-DEVINL s16x8 nt_frag(const char* tile, int row, int chunk) {
-    return *(const s16x8*)(tile + row * 128 + ((chunk ^ nt_swz(row)) << 4));
+template <int BKT> DEVINL s16x8 nt_frag(const char* tile, int row, int chunk) {
+    return *(const s16x8*)(tile + row * (BKT * 2) + ((chunk ^ nt_swz<BKT>(row)) << 4));
 }
 
 template <typename TC> struct Vec4;
@@ -196,17 +203,17 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x) {
     Vec8<TC>::st((TC*)a.C + off, x);
 }
 
-// Row-contiguous epilogue: the wave's 64x64 fp32 accumulator tile goes through its private LDS slab (two 32-row
-// halves, 68-float rows: conflict-free ds_write_b128 / ds_read_b128) so that every global access of the epilogue
-// is 8 lanes x 16 B = one whole 128-B line per row (the direct fragment layout touches 16 lines per instruction,
-// 32 B each, and made the N = 3072 GELU GEMMs store-issue bound).
-template <typename TC, int EPI>
+// Row-contiguous epilogue: the wave's WM x 64 fp32 accumulator tile goes through its private LDS slab (32-row passes,
+// 68-float rows: conflict-free ds_write_b128 / ds_read_b128) so that every global access of the epilogue is
+// 8 lanes x 16 B = one whole 128-B line per row (the direct fragment layout touches 16 lines per instruction, 32 B
+// each, and made the N = 3072 GELU GEMMs store-issue bound).
+template <typename TC, int EPI, int MI>
 DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int64_t m_base, int64_t n_base,
-                          f32x4 (&acc)[4][4]) {
+                          f32x4 (&acc)[MI][4]) {
     constexpr int LDW = 68;
     float* t = (float*)smem + wave * 32 * LDW;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -226,14 +233,14 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
     }
 }
 
-// BM_ x BN_ output tile, one 64x64 sub-tile per wave ((BM_/64) x (BN_/64) waves), NST-stage LDS ring with the DMA
-// of stage t + NST - 1 issued before the MFMAs of stage t and retired by a COUNTED s_waitcnt (loads stay in flight
-// across the raw s_barrier).
-template <int BM_, int BN_, int NST, int EPI>
-__global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
-    constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / 64) * WAVES_N;
-    constexpr int A_BYTES = BM_ * BK * 2, ST_BYTES = (BM_ + BN_) * BK * 2;
-    constexpr int A_SEGS = BM_ / 8 / NWAVES, B_SEGS = BN_ / 8 / NWAVES;  // 1-KiB DMA pieces per wave per stage
+// BM_ x BN_ output tile, one WM x 64 sub-tile per wave ((BM_/WM) x (BN_/64) waves), BKT-deep reduction steps, NST-stage
+// LDS ring with the DMA of stage t + NST - 1 issued before the MFMAs of stage t and retired by a COUNTED s_waitcnt
+// (loads stay in flight across the raw s_barrier).
+template <int BM_, int BN_, int BKT, int NST, int WM, int EPI>
+__global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
+    constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / WM) * WAVES_N, MI = WM / 16;
+    constexpr int A_BYTES = BM_ * BKT * 2, ST_BYTES = (BM_ + BN_) * BKT * 2;
+    constexpr int A_SEGS = A_BYTES / 1024 / NWAVES, B_SEGS = BN_ * BKT * 2 / 1024 / NWAVES;  // DMA pieces per wave
     constexpr int G = A_SEGS + B_SEGS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -246,18 +253,18 @@ __global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
     const int64_t m0 = (int64_t)(wg / tiles_n) * BM_;
     const int64_t n0 = (int64_t)(wg % tiles_n) * BN_;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (int)(a.K / BK);
+    const int nt = (int)(a.K / BKT);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) {
         if (s < nt) {
-            nt_stage<A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)s * BK, smem + s * ST_BYTES, wave, lane);
-            nt_stage<B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)s * BK, smem + s * ST_BYTES + A_BYTES, wave, lane);
+            nt_stage<BKT, A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)s * BKT, smem + s * ST_BYTES, wave, lane);
+            nt_stage<BKT, B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)s * BKT, smem + s * ST_BYTES + A_BYTES, wave, lane);
         }
     }
 
@@ -271,20 +278,20 @@ __global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
         asm volatile("" ::: "memory");
         if (t + NST - 1 < nt) {
             char* nxt = smem + nxt_s * ST_BYTES;
-            nt_stage<A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)(t + NST - 1) * BK, nxt, wave, lane);
-            nt_stage<B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)(t + NST - 1) * BK, nxt + A_BYTES, wave, lane);
+            nt_stage<BKT, A_SEGS, NWAVES>(a.A, a.lda, m0, a.M, (int64_t)(t + NST - 1) * BKT, nxt, wave, lane);
+            nt_stage<BKT, B_SEGS, NWAVES>(a.B, a.ldb, n0, a.N, (int64_t)(t + NST - 1) * BKT, nxt + A_BYTES, wave, lane);
         }
         const char* At = smem + cur_s * ST_BYTES;
         const char* Bt = At + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            s16x8 af[4], bfr[4];
+        for (int kk = 0; kk < BKT / 32; ++kk) {
+            s16x8 af[MI], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = nt_frag(At, wr * 64 + i * 16 + frow, kk * 4 + fchunk);
+            for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<BKT>(Bt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = nt_frag(Bt, wc * 64 + j * 16 + frow, kk * 4 + fchunk);
+            for (int i = 0; i < MI; ++i) af[i] = nt_frag<BKT>(At, wr * WM + i * 16 + frow, kk * 4 + fchunk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     // D'[n][m] = sum_k B[n][k] * A[m][k]: each lane ends with 4 consecutive n of one m
@@ -299,14 +306,14 @@ __global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
     if (a.rows_epi) {
         __builtin_amdgcn_s_barrier();  // every wave has consumed its last stage: the ring is free for the C slabs
         asm volatile("" ::: "memory");
-        if (a.c_f32) epilogue_rows<float, EPI>(a, smem, wave, lane, m0 + wr * 64, n0 + wc * 64, acc);
-        else epilogue_rows<bf16_t, EPI>(a, smem, wave, lane, m0 + wr * 64, n0 + wc * 64, acc);
+        if (a.c_f32) epilogue_rows<float, EPI, MI>(a, smem, wave, lane, m0 + wr * WM, n0 + wc * 64, acc);
+        else epilogue_rows<bf16_t, EPI, MI>(a, smem, wave, lane, m0 + wr * WM, n0 + wc * 64, acc);
         return;
     }
     // direct epilogue (N % 8 != 0): lane holds C[m = .. + (lane & 15)][n = .. + 4 * (lane >> 4) + 0..3]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wr * WM + i * 16 + (lane & 15);
         if (m >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -326,13 +333,17 @@ __global__ __launch_bounds__((BM_ / 64) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
 // 0,1) x 32 B; the swizzle sends those 8 rows to 8 different 32-B column pairs -> all 64 banks, conflict free.
 DEVINL int tn_swz(int row) { return (((row & 3) << 1) | ((row >> 3) & 1)) << 1; }
 
+// stage a [64 reduction rows][COLS] bf16 operand tile: 1-KiB DMA pieces = 1024 / (2 * COLS) rows each
+template <int COLS, int SEGS_PER_WAVE, int NWAVES>
 DEVINL void tn_stage(const bf16_t* G, int64_t ld, int64_t r0, int64_t r_end, int64_t n0, char* tile, int wave,
                      int lane) {
+    constexpr int CPR = COLS / 8;   // 16-B chunks per row (16 or 32)
+    constexpr int RPS = 64 / CPR;   // rows per piece (4 or 2)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int seg = q * 4 + wave;  // 1 KiB = 4 rows of 256 B
-        const int row = seg * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ tn_swz(row);
+    for (int q = 0; q < SEGS_PER_WAVE; ++q) {
+        const int seg = q * NWAVES + wave;
+        const int row = seg * RPS + lane / CPR;
+        const int chunk = (lane % CPR) ^ tn_swz(row);  // XOR < 16: stays inside the row's aligned 256-B half
         const int64_t grow = r0 + row;
         const void* src = (grow < r_end) ? (const void*)(G + grow * ld + n0 + chunk * 8)
                                          : (const void*)((const char*)g_m3ae_zero_page + (lane & 15) * 16);
@@ -342,77 +353,83 @@ DEVINL void tn_stage(const bf16_t* G, int64_t ld, int64_t r0, int64_t r_end, int
 
 // MFMA 16x16x32 operand whose k index runs over tile ROWS kbase..kbase+31 and whose row/col index is tile
 // column ncol0 + (lane & 15): two transposing reads of 4 rows x 16 columns each.
+template <int COLS>
 DEVINL s16x8 tn_frag(const char* tile, int kbase, int ncol0, int lane) {
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int col = ncol0 + 4 * p;
     const int chunk = col >> 3, within = (col & 7) * 2;
     const int r1 = kbase + 8 * g + q, r2 = r1 + 4;
-    const char* a1 = tile + r1 * 256 + ((chunk ^ tn_swz(r1)) << 4) + within;
-    const char* a2 = tile + r2 * 256 + ((chunk ^ tn_swz(r2)) << 4) + within;
+    const char* a1 = tile + r1 * (COLS * 2) + ((chunk ^ tn_swz(r1)) << 4) + within;
+    const char* a2 = tile + r2 * (COLS * 2) + ((chunk ^ tn_swz(r2)) << 4) + within;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a2);
     return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
-    // C[n1][n2] (+)= alpha * sum_r A[r][n1] * B[r][n2];  a.M = N1, a.N = N2, a.K = reduction rows
+// C[n1][n2] (+)= alpha * sum_r A[r][n1] * B[r][n2];  a.M = N1, a.N = N2, a.K = reduction rows.
+// BM_ x BN_ output tile, one WM x 64 sub-tile per wave, 64 reduction rows per step, 2-stage ring.
+template <int BM_, int BN_, int WM>
+__global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
+    constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / WM) * WAVES_N, MI = WM / 16;
+    constexpr int A_BYTES = BM_ * BK * 2, ST_BYTES = (BM_ + BN_) * BK * 2;
+    constexpr int A_SEGS = A_BYTES / 1024 / NWAVES, B_SEGS = BN_ * BK * 2 / 1024 / NWAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
-    const unsigned tiles_n = (unsigned)(a.N / BN);
-    const unsigned tiles = (unsigned)(a.M / BM) * tiles_n;
+    const unsigned tiles_n = (unsigned)(a.N / BN_);
+    const unsigned tiles = (unsigned)(a.M / BM_) * tiles_n;
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned tile_id = wg % tiles, split = wg / tiles;
-    const int64_t m0 = (int64_t)(tile_id / tiles_n) * BM;
-    const int64_t n0 = (int64_t)(tile_id % tiles_n) * BN;
+    const int64_t m0 = (int64_t)(tile_id / tiles_n) * BM_;
+    const int64_t n0 = (int64_t)(tile_id % tiles_n) * BN_;
     const int64_t r_begin = (int64_t)split * a.k_chunk;
     int64_t r_end = r_begin + a.k_chunk;
     if (r_end > a.K) r_end = a.K;
     if (r_begin >= r_end) return;  // whole workgroup: uniform
     const int nt = (int)((r_end - r_begin + BK - 1) / BK);
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // bias gradient rides along: the waves of the first output-column tile also multiply their A^T fragments by a
     // ones fragment (every column of that product is the row sum of A^T = the column sum of dY)
     const bool do_rowsum = a.a_rowsum != nullptr && n0 == 0 && wc == 0;
-    f32x4 rsum[4];
+    f32x4 rsum[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
-    tn_stage(a.A, a.lda, r_begin, r_end, m0, smem, wave, lane);
-    tn_stage(a.B, a.ldb, r_begin, r_end, n0, smem + BM * BK * 2, wave, lane);
+    tn_stage<BM_, A_SEGS, NWAVES>(a.A, a.lda, r_begin, r_end, m0, smem, wave, lane);
+    tn_stage<BN_, B_SEGS, NWAVES>(a.B, a.ldb, r_begin, r_end, n0, smem + A_BYTES, wave, lane);
 
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        char* cur = smem + (t & 1) * STAGE_BYTES;
+        char* cur = smem + (t & 1) * ST_BYTES;
         if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+            char* nxt = smem + ((t + 1) & 1) * ST_BYTES;
             const int64_t r0 = r_begin + (int64_t)(t + 1) * BK;
-            tn_stage(a.A, a.lda, r0, r_end, m0, nxt, wave, lane);
-            tn_stage(a.B, a.ldb, r0, r_end, n0, nxt + BM * BK * 2, wave, lane);
+            tn_stage<BM_, A_SEGS, NWAVES>(a.A, a.lda, r0, r_end, m0, nxt, wave, lane);
+            tn_stage<BN_, B_SEGS, NWAVES>(a.B, a.ldb, r0, r_end, n0, nxt + A_BYTES, wave, lane);
         }
         const char* At = cur;
-        const char* Bt = cur + BM * BK * 2;
+        const char* Bt = cur + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            s16x8 af[4], bfr[4];
+            s16x8 af[MI], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tn_frag(At, kk * 32, wr * 64 + i * 16, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = tn_frag<BN_>(Bt, kk * 32, wc * 64 + j * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(Bt, kk * 32, wc * 64 + j * 16, lane);
+            for (int i = 0; i < MI; ++i) af[i] = tn_frag<BM_>(At, kk * 32, wr * WM + i * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     // D[n1][n2] = sum_r A^T[n1][r] * B[r][n2]
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
                         __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
             if (do_rowsum) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
                     rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), rsum[i], 0, 0, 0);
             }
@@ -428,21 +445,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
     }
     if (do_rowsum && (lane & 15) == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(a.a_rowsum + m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r, rsum[i][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(a.a_rowsum + m0 + wr * WM + i * 16 + 4 * (lane >> 4) + r, rsum[i][r]);
     }
 
     // lane holds D[n1 = .. + 4 * (lane >> 4) + reg][n2 = .. + (lane & 15)]
     float* C = (float*)a.C;
     const bool atomic = a.splits > 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t n1 = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+                const int64_t n1 = m0 + wr * WM + i * 16 + 4 * (lane >> 4) + r;
                 const int64_t n2 = n0 + wc * 64 + j * 16 + (lane & 15);
                 float* p = C + n1 * a.ldc + n2;
                 const float x = acc[i][j][r] * a.alpha;
@@ -461,31 +478,52 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : 0;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
+static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : 0;
+static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
+    if (key == 1) { g_tn_variant = value; return 0; }
     return M3AE_ERR_ARG;
 }
 
-template <int BM_, int BN_, int NST, int EPI>
+template <int BM_, int BN_, int BKT, int NST, int WM, int EPI>
 static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
-    constexpr int lds = NST * (BM_ + BN_) * BK * 2;
-    constexpr int threads = (BM_ / 64) * (BN_ / 64) * 64;
+    constexpr int nwaves = (BM_ / WM) * (BN_ / 64);
+    constexpr int ring = NST * (BM_ + BN_) * BKT * 2, slabs = nwaves * 32 * 68 * 4;
+    constexpr int lds = ring > slabs ? ring : slabs;
+    constexpr int threads = nwaves * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM_, BN_, NST, EPI>,
+        hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM_, BN_, BKT, NST, WM, EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t tiles = cdiv(a.M, BM_) * cdiv(a.N, BN_);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM_, BN_, NST, EPI>), dim3((unsigned)tiles), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM_, BN_, BKT, NST, WM, EPI>), dim3((unsigned)tiles), dim3(threads), lds, s,
+                       a);
     return hip_launch_status();
 }
 
+// variants (m3ae_set_tuning key 0):
+//   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU
+//   1: 256x128 tile, BK 64, 3 stages, 8 waves x (64x64)   -- 144 KiB LDS, 1 workgroup / CU, counted vmcnt
+//   2: 256x128 tile, BK 32, 2 stages, 4 waves x (128x64)  -- 48 KiB LDS, 2 workgroups / CU, 25 % less L2->LDS traffic
+//      and LDS-read traffic per FLOP (12 fragment reads per 32 MFMAs)
+//   3: 256x256 tile, BK 32, 4 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU: half the L1->LDS bytes/FLOP
+//   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
-    if (g_nt_variant == 1 && a.M > 128) return launch_nt_t<256, 128, 3, EPI>(a, s);
-    return launch_nt_t<128, 128, 2, EPI>(a, s);
+    if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
+        const bool big = a.M >= 4096 && a.N >= 512;
+        if (big && EPI == EPI_PLAIN) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
+        if (big) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
+        return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
+    }
+    if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
+    if (g_nt_variant == 3 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
+    if (g_nt_variant == 2 && a.M > 128) return launch_nt_t<256, 128, 32, 2, 128, EPI>(a, s);
+    if (g_nt_variant == 1 && a.M > 128) return launch_nt_t<256, 128, 64, 3, 64, EPI>(a, s);
+    return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
 }
 
 static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
@@ -507,17 +545,14 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     return launch_nt_v<EPI_ANY>(a, s);
 }
 
-static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
-    // C[M=N1][N=N2] += alpha * sum_k A[m][k] B[k][n] with a_sm == 1 (A stored [K][N1]) and b_sn == 1
-    MfmaArgs a{};
-    a.A = (const bf16_t*)d.A; a.lda = d.a_sk;
-    a.B = (const bf16_t*)d.B; a.ldb = d.b_sk;
-    a.C = d.C; a.ldc = d.c_sm;
-    a.M = d.M; a.N = d.N; a.K = d.K;
-    a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
-    const int64_t tiles = (d.M / BM) * (d.N / BN);
+template <int BM_, int BN_, int WM>
+static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
+    constexpr int lds = 2 * (BM_ + BN_) * BK * 2;
+    constexpr int threads = (BM_ / WM) * (BN_ / 64) * 64;
+    const int64_t tiles = (d.M / BM_) * (d.N / BN_);
     const int64_t ksteps = cdiv(d.K, BK);
-    int64_t splits = 768 / tiles;  // aim at ~3 workgroups per CU
+    const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
+    int64_t splits = target / tiles;
     if (splits > ksteps / 4) splits = ksteps / 4;
     if (splits < 1) splits = 1;
     if (!d.accumulate) splits = 1;
@@ -527,11 +562,24 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.splits = (int)splits;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<BM_, BN_, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)(tiles * splits)), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM_, BN_, WM>), dim3((unsigned)(tiles * splits)), dim3(threads), lds, s, a);
     return hip_launch_status();
+}
+
+static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
+    // C[M=N1][N=N2] += alpha * sum_k A[m][k] B[k][n] with a_sm == 1 (A stored [K][N1]) and b_sn == 1
+    MfmaArgs a{};
+    a.A = (const bf16_t*)d.A; a.lda = d.a_sk;
+    a.B = (const bf16_t*)d.B; a.ldb = d.b_sk;
+    a.C = d.C; a.ldc = d.c_sm;
+    a.M = d.M; a.N = d.N; a.K = d.K;
+    a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
+    // variant 1: 256x256 tile, 8 waves x (128x64): half the operand re-read traffic of the 128x128 tile
+    if (g_tn_variant == 1 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096) return launch_tn_t<256, 256, 128>(a, d, s);
+    return launch_tn_t<128, 128, 64>(a, d, s);
 }
 
 extern "C" int m3ae_gemm(const m3ae_gemm_desc* dp, void* stream) {

@@ -52,7 +52,7 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
         assert ops.last_gemm_path() == expect
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
     from m3ae_amd import _lib
@@ -65,10 +65,11 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
         y2, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32, force_generic=True)
         assert ops.last_gemm_path() == "generic"
         close(y1, y2, 1e-5, 1e-5, msg=f"{M}x{N}x{K}")
-    _lib.lib().m3ae_set_tuning(0, 0)
+    _lib.lib().m3ae_set_tuning(0, -1)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (577 * 2, 768, 768), (1000, 2304, 768), (4616, 768, 3072), (37, 128, 256)])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (577 * 2, 768, 768), (1000, 2304, 768), (4616, 768, 3072), (37, 128, 256),
+                                   (4616, 256, 512), (9000, 768, 768)])
 def test_gemm_wgrad_tn(M, N, K):
     """dW[N,K] += dY[M,N]^T X[M,K]: MFMA TN kernel (transposing LDS reads, split-K atomics), fp32 accumulate."""
     dy, x = rnd(M, N, dtype=torch.bfloat16, seed=7), rnd(M, K, dtype=torch.bfloat16, seed=8)

@@ -9,6 +9,7 @@ import torch  # noqa: E402
 from m3ae_amd import _lib, ops  # noqa: E402
 
 B = int(os.environ.get("B", 64))
+VARS = (0, 4, -1)
 M = B * 577
 NT_SHAPES = [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768),
              (4096, 4096, 4096), (8192, 8192, 8192)]
@@ -37,16 +38,18 @@ def main():
         y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
         res = []
         for rnd in range(2):
-            for v in (0, 1):
+            for v in VARS:
                 L.m3ae_set_tuning(0, v)
                 ms = time_it(lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k))
                 res.append((v, ms))
-        best = {v: min(ms for vv, ms in res if vv == v) for v in (0, 1)}
-        print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in (0, 1)), flush=True)
-    L.m3ae_set_tuning(0, 0)
-    # epilogue-heavy forms on the dominant shapes (variant 0)
+        best = {v: min(ms for vv, ms in res if vv == v) for v in VARS}
+        print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in VARS), flush=True)
+    # epilogue-heavy forms on the dominant shapes
     m = M
-    for (n, k, kind) in [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (768, 768, "bias+res"), (768, 3072, "bias+res")]:
+    for vv in (0, 3):
+      L.m3ae_set_tuning(0, vv)
+      print("variant", vv)
+      for (n, k, kind) in [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (768, 768, "bias+res"), (768, 3072, "bias+res")]:
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
         y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
@@ -61,12 +64,18 @@ def main():
             fn = lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k, bias=b, residual=aux)
         ms = time_it(fn)
         print(f"NT {m:6d}x{n:5d}x{k:5d} {kind:12s}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
+    L.m3ae_set_tuning(0, 0)
     for (m, n, k) in TN_SHAPES:
         dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         g = torch.zeros(n, k, device=dev)
-        ms = time_it(lambda: ops.gemm(dy, 1, n, x, k, 1, g, k, n, k, m, accumulate=True))
-        print(f"TN red={m:6d} out {n:5d}x{k:5d}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
+        out = []
+        for tv in (0, 1):
+            L.m3ae_set_tuning(1, tv)
+            ms = time_it(lambda: ops.gemm(dy, 1, n, x, k, 1, g, k, n, k, m, accumulate=True))
+            out.append(f"tv{tv}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s")
+        print(f"TN red={m:6d} out {n:5d}x{k:5d}: " + "  ".join(out), flush=True)
+    L.m3ae_set_tuning(1, 0)
 
 
 if __name__ == "__main__":
