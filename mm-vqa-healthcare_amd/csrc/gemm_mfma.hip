@@ -369,11 +369,12 @@ DEVINL s16x8 tn_frag(const char* tile, int kbase, int ncol0, int lane) {
 
 // C[n1][n2] (+)= alpha * sum_r A[r][n1] * B[r][n2];  a.M = N1, a.N = N2, a.K = reduction rows.
 // BM_ x BN_ output tile, one WM x 64 sub-tile per wave, 64 reduction rows per step, 2-stage ring.
-template <int BM_, int BN_, int WM>
+template <int BM_, int BN_, int WM, int BKR, int NST>
 __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_tn_bf16_kernel(MfmaArgs a) {
     constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / WM) * WAVES_N, MI = WM / 16;
-    constexpr int A_BYTES = BM_ * BK * 2, ST_BYTES = (BM_ + BN_) * BK * 2;
-    constexpr int A_SEGS = A_BYTES / 1024 / NWAVES, B_SEGS = BN_ * BK * 2 / 1024 / NWAVES;
+    constexpr int A_BYTES = BM_ * BKR * 2, ST_BYTES = (BM_ + BN_) * BKR * 2;
+    constexpr int A_SEGS = A_BYTES / 1024 / NWAVES, B_SEGS = BN_ * BKR * 2 / 1024 / NWAVES;
+    constexpr int G = A_SEGS + B_SEGS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_tn_bf16_
     int64_t r_end = r_begin + a.k_chunk;
     if (r_end > a.K) r_end = a.K;
     if (r_begin >= r_end) return;  // whole workgroup: uniform
-    const int nt = (int)((r_end - r_begin + BK - 1) / BK);
+    const int nt = (int)((r_end - r_begin + BKR - 1) / BKR);
 
     f32x4 acc[MI][4];
 #pragma unroll
@@ -406,23 +407,30 @@ __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_tn_bf16_
     for (int i = 0; i < MI; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
-    tn_stage<BM_, A_SEGS, NWAVES>(a.A, a.lda, r_begin, r_end, m0, smem, wave, lane);
-    tn_stage<BN_, B_SEGS, NWAVES>(a.B, a.ldb, r_begin, r_end, n0, smem + A_BYTES, wave, lane);
-
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        if (s < nt) {
+            const int64_t r0 = r_begin + (int64_t)s * BKR;
+            tn_stage<BM_, A_SEGS, NWAVES>(a.A, a.lda, r0, r_end, m0, smem + s * ST_BYTES, wave, lane);
+            tn_stage<BN_, B_SEGS, NWAVES>(a.B, a.ldb, r0, r_end, n0, smem + s * ST_BYTES + A_BYTES, wave, lane);
+        }
+    }
+    int cur_s = 0, nxt_s = NST - 1;
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char* cur = smem + (t & 1) * ST_BYTES;
-        if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * ST_BYTES;
-            const int64_t r0 = r_begin + (int64_t)(t + 1) * BK;
+        if (t + NST - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) {
+            char* nxt = smem + nxt_s * ST_BYTES;
+            const int64_t r0 = r_begin + (int64_t)(t + NST - 1) * BKR;
             tn_stage<BM_, A_SEGS, NWAVES>(a.A, a.lda, r0, r_end, m0, nxt, wave, lane);
             tn_stage<BN_, B_SEGS, NWAVES>(a.B, a.ldb, r0, r_end, n0, nxt + A_BYTES, wave, lane);
         }
-        const char* At = cur;
-        const char* Bt = cur + A_BYTES;
+        const char* At = smem + cur_s * ST_BYTES;
+        const char* Bt = At + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BKR / 32; ++kk) {
             s16x8 af[MI], bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = tn_frag<BN_>(Bt, kk * 32, wc * 64 + j * 16, lane);
@@ -442,6 +450,9 @@ __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_tn_bf16_
                         __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), rsum[i], 0, 0, 0);
             }
         }
+        asm volatile("" ::: "memory");
+        cur_s = cur_s + 1 == NST ? 0 : cur_s + 1;
+        nxt_s = nxt_s + 1 == NST ? 0 : nxt_s + 1;
     }
     if (do_rowsum && (lane & 15) == 0) {
 #pragma unroll
@@ -478,7 +489,7 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : 0;
+static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : 2;
 static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
@@ -519,6 +530,7 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         if (big) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
+    if (g_nt_variant == 5) return launch_nt_t<128, 128, 32, 2, 64, EPI>(a, s);  // 34 KiB LDS: 4 workgroups / CU
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
     if (g_nt_variant == 3 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
     if (g_nt_variant == 2 && a.M > 128) return launch_nt_t<256, 128, 32, 2, 128, EPI>(a, s);
@@ -545,27 +557,29 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     return launch_nt_v<EPI_ANY>(a, s);
 }
 
-template <int BM_, int BN_, int WM>
+template <int BM_, int BN_, int WM, int BKR, int NST>
 static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
-    constexpr int lds = 2 * (BM_ + BN_) * BK * 2;
+    constexpr int lds = NST * (BM_ + BN_) * BKR * 2;
     constexpr int threads = (BM_ / WM) * (BN_ / 64) * 64;
     const int64_t tiles = (d.M / BM_) * (d.N / BN_);
-    const int64_t ksteps = cdiv(d.K, BK);
+    const int64_t ksteps = cdiv(d.K, 64);
     const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
     int64_t splits = target / tiles;
     if (splits > ksteps / 4) splits = ksteps / 4;
     if (splits < 1) splits = 1;
     if (!d.accumulate) splits = 1;
     const int64_t steps_per = cdiv(ksteps, splits);
-    a.k_chunk = steps_per * BK;
+    a.k_chunk = steps_per * 64;
     splits = cdiv(ksteps, steps_per);
     a.splits = (int)splits;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<BM_, BN_, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<BM_, BN_, WM, BKR, NST>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM_, BN_, WM>), dim3((unsigned)(tiles * splits)), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<BM_, BN_, WM, BKR, NST>), dim3((unsigned)(tiles * splits)), dim3(threads), lds,
+                       s, a);
     return hip_launch_status();
 }
 
@@ -578,8 +592,11 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K;
     a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
     // variant 1: 256x256 tile, 8 waves x (128x64): half the operand re-read traffic of the 128x128 tile
-    if (g_tn_variant == 1 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096) return launch_tn_t<256, 256, 128>(a, d, s);
-    return launch_tn_t<128, 128, 64>(a, d, s);
+    if (g_tn_variant == 1 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096) return launch_tn_t<256, 256, 128, 64, 2>(a, d, s);
+    if (g_tn_variant == 2) return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);  // 32 KiB LDS: 3 workgroups / CU
+    if (g_tn_variant == 3) return launch_tn_t<128, 128, 64, 32, 4>(a, d, s);  // 4-stage ring of 32-row steps, counted vmcnt
+    if (g_tn_variant == 4) return launch_tn_t<128, 128, 64, 64, 3>(a, d, s);  // 3-stage ring, 96 KiB, 1 workgroup / CU
+    return launch_tn_t<128, 128, 64, 64, 2>(a, d, s);
 }
 
 extern "C" int m3ae_gemm(const m3ae_gemm_desc* dp, void* stream) {
