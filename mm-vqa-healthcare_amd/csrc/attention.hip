@@ -15,6 +15,7 @@
 // fp32 ("parity mode"): the reference's own algorithm (bert_model.py:301-340): S = QK^T/sqrt(dh) + mask
 //   materialised in a caller workspace, row softmax, PV, through the generic GEMM kernel.
 #include "common.h"
+#include <stdlib.h>
 
 int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
@@ -527,6 +528,320 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) 
     }
 }
 
+// =========================================================================================================
+// Workgroup-cooperative variants ("coop"): the 4 waves of a workgroup own consecutive row tiles of ONE (batch, head)
+// and share every streamed tile through LDS: one coalesced 16-B-per-lane global load per tile for the whole
+// workgroup (8 lanes = one 128-B row), instead of each wave fetching its own copy with 32-B-per-line fragment
+// loads.  L2 -> CU traffic drops 4x and is fully coalesced (the per-wave kernels ran at the ~8 TB/s L2 fabric
+// ceiling).  Two LDS images per streamed operand where both kinds of MFMA fragment are needed:
+//   row image  [32][128 B], chunk ^= (row >> 1) & 7  -> conflict-free ds_read_b128 row fragments
+//   tr  image  [32][192 B]                           -> conflict-free ds_read_b64_tr_b16 transposed fragments
+// Double-buffered, one __syncthreads() per streamed tile.
+// =========================================================================================================
+constexpr int RIMG = 32 * 128;  // row image bytes
+
+DEVINL int rswz(int row) { return (row >> 1) & 7; }
+// cooperative tile fetch: thread t of 256 -> row t >> 3, 16-B chunk t & 7 of a [32][64] bf16 tile
+DEVINL s16x8 coop_load(const bf16_t* base, int64_t sl, int64_t row0, int64_t nrows, int t) {
+    int64_t row = row0 + (t >> 3);
+    row = row < nrows ? row : nrows - 1;
+    return *(const s16x8*)(base + row * sl + (t & 7) * 8);
+}
+DEVINL void put_row_img(char* img, s16x8 v, int t) {
+    const int row = t >> 3, ch = t & 7;
+    *(s16x8*)(img + row * 128 + ((ch ^ rswz(row)) << 4)) = v;
+}
+DEVINL void put_tr_img(char* img, s16x8 v, int t) { *(s16x8*)(img + (t >> 3) * VRS + (t & 7) * 16) = v; }
+DEVINL s16x8 get_row_frag(const char* img, int r, int ks, int h) {
+    return *(const s16x8*)(img + r * 128 + (((2 * ks + h) ^ rswz(r)) << 4));
+}
+
+template <int NQ, bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
+    constexpr int BUF = RIMG + TILE_LDS;  // K row image + V tr image
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * NQ);
+    const bool active = q0 < a.Lq;  // wave-uniform; inactive waves still help with the cooperative loads
+
+    int64_t qi[NQ];
+    s16x8 qf[NQ][4];
+    const float* brow[NQ];
+    f32x16 o[NQ][2];
+    float m[NQ], l[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        qi[n] = q0 + 32 * n + r;
+        const int64_t qrow = qi[n] < a.Lq ? qi[n] : a.Lq - 1;
+        const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[n][ks] = row_frag(qp, ks, h);
+        brow[n] = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+        o[n][0] = zero16(); o[n][1] = zero16();
+        m[n] = -1e30f; l[n] = 0.f;
+    }
+    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
+    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
+    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
+    const int nkt = (int)((a.Lk + 31) / 32);
+
+    s16x8 kreg = coop_load(kbase, a.k_sl, 0, a.Lk, t);
+    s16x8 vreg = coop_load(vbase, a.v_sl, 0, a.Lk, t);
+    put_row_img(lds, kreg, t);
+    put_tr_img(lds + RIMG, vreg, t);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool last = kt + 1 == nkt;
+        if (!last) {
+            kreg = coop_load(kbase, a.k_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+            vreg = coop_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+        }
+        const char* kimg = lds + (kt & 1) * BUF;
+        const char* vimg = kimg + RIMG;
+        if (active) {
+            s16x8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = get_row_frag(kimg, r, ks, h);
+            f32x16 s[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                s[n] = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s[n] = mfma32(kf[ks], qf[n][ks], s[n]);  // S^T[key][q] = K . Q^T
+            }
+            const int64_t key0 = (int64_t)kt * 32;
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
+                else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const s16x8 v0 = tr_frag(vimg, 0, ss, lane), v1 = tr_frag(vimg, 1, ss, lane);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    const s16x8 pb = pack_acc(s[n], ss);
+                    o[n][0] = mfma32(v0, pb, o[n][0]);  // O^T[d][q] += V^T[d][key] . P^T[key][q]
+                    o[n][1] = mfma32(v1, pb, o[n][1]);
+                }
+            }
+        }
+        if (!last) {
+            char* nb = lds + ((kt + 1) & 1) * BUF;
+            put_row_img(nb, kreg, t);
+            put_tr_img(nb + RIMG, vreg, t);
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float ltot = l[n] + __shfl_xor(l[n], 32, 64);
+        if (qi[n] < a.Lq) {
+            store_rows(a.o + b * a.o_sb + qi[n] * a.o_sl + head * 64, o[n][0], o[n][1], 1.0f / ltot, h);
+            if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi[n]] = m[n] + log2f(ltot);
+        }
+    }
+}
+
+template <bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
+    constexpr int BUF = RIMG + TILE_LDS + RIMG;  // K row image, K tr image, V row image
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < a.Lq;
+
+    const int64_t qi = q0 + r;
+    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
+    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+    const bf16_t* dop = a.d_o + b * a.o_sb + qrow * a.o_sl + head * 64;
+    s16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(qp, ks, h); dof[ks] = row_frag(dop, ks, h); }
+    const float lse = a.lse[(b * a.H + head) * a.lse_stride + qrow];
+    const float dlt = a.delta[(b * a.H + head) * a.lse_stride + qrow];
+
+    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
+    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
+    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
+    const float* brow = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+    float* dbrow = (BIAS && a.d_pos_bias) ? a.d_pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
+
+    f32x16 g0 = zero16(), g1 = zero16();
+    const int nkt = (int)((a.Lk + 31) / 32);
+    s16x8 kreg = coop_load(kbase, a.k_sl, 0, a.Lk, t);
+    s16x8 vreg = coop_load(vbase, a.v_sl, 0, a.Lk, t);
+    put_row_img(lds, kreg, t);
+    put_tr_img(lds + RIMG, kreg, t);
+    put_row_img(lds + RIMG + TILE_LDS, vreg, t);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool last = kt + 1 == nkt;
+        if (!last) {
+            kreg = coop_load(kbase, a.k_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+            vreg = coop_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+        }
+        const char* kimg = lds + (kt & 1) * BUF;
+        const char* ktr = kimg + RIMG;
+        const char* vimg = ktr + TILE_LDS;
+        if (active) {
+            s16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = get_row_frag(kimg, r, ks, h); vf[ks] = get_row_frag(vimg, r, ks, h); }
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t key = (int64_t)kt * 32 + crow(reg, h);
+                float x = s[reg] * a.scale_log2;
+                bool valid = true;
+                if (MASK || BIAS || last) {
+                    const int64_t kc = key < a.Lk ? key : a.Lk - 1;
+                    if (MASK) x = fmaf(mrow[kc], LOG2E, x);
+                    if (BIAS) x = fmaf(brow[kc], LOG2E, x);
+                    valid = key < a.Lk;
+                }
+                if (CAUSAL) valid = valid && key <= qi;
+                const float p = valid ? fast_exp2(x - lse) : 0.f;
+                const float ds = p * (dp[reg] - dlt);
+                if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
+                s[reg] = ds;
+            }
+            const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+            // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+            g0 = mfma32(tr_frag(ktr, 0, 0, lane), d0, g0);
+            g1 = mfma32(tr_frag(ktr, 1, 0, lane), d0, g1);
+            g0 = mfma32(tr_frag(ktr, 0, 1, lane), d1, g0);
+            g1 = mfma32(tr_frag(ktr, 1, 1, lane), d1, g1);
+        }
+        if (!last) {
+            char* nb = lds + ((kt + 1) & 1) * BUF;
+            put_row_img(nb, kreg, t);
+            put_tr_img(nb + RIMG, kreg, t);
+            put_row_img(nb + RIMG + TILE_LDS, vreg, t);
+        }
+        __syncthreads();
+    }
+    if (active && qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
+}
+
+template <bool MASK, bool BIAS, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) {
+    constexpr int BUF = 2 * (RIMG + TILE_LDS);  // Q row, Q tr, dO row, dO tr
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const bool active = k0 < a.Lk;
+
+    const int64_t ki = k0 + r;
+    const int64_t krow = ki < a.Lk ? ki : a.Lk - 1;
+    const bf16_t* kp = a.k + b * a.k_sb + krow * a.k_sl + head * 64;
+    const bf16_t* vp = a.v + b * a.v_sb + krow * a.v_sl + head * 64;
+    s16x8 kfb[4], vfb[4];  // B operands: K^T[d][key], V^T[d][key]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kfb[ks] = row_frag(kp, ks, h); vfb[ks] = row_frag(vp, ks, h); }
+    const float mk = MASK ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
+    const bool key_ok = ki < a.Lk;
+
+    const bf16_t* qbase = a.q + b * a.q_sb + head * 64;
+    const bf16_t* dobase = a.d_o + b * a.o_sb + head * 64;
+    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;
+    const float* drow = a.delta + (b * a.H + head) * a.lse_stride;
+    const float* bcol = BIAS ? a.pos_bias + (int64_t)head * a.Lq * a.Lk + krow : nullptr;
+
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    const int nqt = (int)((a.Lq + 31) / 32);
+    s16x8 qreg = coop_load(qbase, a.q_sl, 0, a.Lq, t);
+    s16x8 doreg = coop_load(dobase, a.o_sl, 0, a.Lq, t);
+    put_row_img(lds, qreg, t);
+    put_tr_img(lds + RIMG, qreg, t);
+    put_row_img(lds + RIMG + TILE_LDS, doreg, t);
+    put_tr_img(lds + 2 * RIMG + TILE_LDS, doreg, t);
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+        const bool last = qt + 1 == nqt;
+        if (!last) {
+            qreg = coop_load(qbase, a.q_sl, (int64_t)(qt + 1) * 32, a.Lq, t);
+            doreg = coop_load(dobase, a.o_sl, (int64_t)(qt + 1) * 32, a.Lq, t);
+        }
+        const char* qimg = lds + (qt & 1) * BUF;
+        const char* qtr = qimg + RIMG;
+        const char* doimg = qtr + TILE_LDS;
+        const char* dotr = doimg + RIMG;
+        if (active) {
+            f32x4 lse4[4], dl4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                lse4[g4] = *(const f32x4*)(lrow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
+                dl4[g4] = *(const f32x4*)(drow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
+            }
+            s16x8 qfa[4], dofa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { qfa[ks] = get_row_frag(qimg, r, ks, h); dofa[ks] = get_row_frag(doimg, r, ks, h); }
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S[q][key]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP[q][key] = dO . V^T
+            f32x16 p;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
+                bool valid = key_ok;
+                if (last) valid = valid && qq < a.Lq;
+                if (CAUSAL) valid = valid && ki <= qq;
+                float x = fmaf(s[reg], a.scale_log2, mk);
+                if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
+                const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
+                p[reg] = pv;
+                s[reg] = pv * (dp[reg] - dl4[reg >> 2][reg & 3]);
+            }
+            const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
+            const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+            // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+            dv0 = mfma32(tr_frag(dotr, 0, 0, lane), p0, dv0);
+            dv1 = mfma32(tr_frag(dotr, 1, 0, lane), p0, dv1);
+            dv0 = mfma32(tr_frag(dotr, 0, 1, lane), p1, dv0);
+            dv1 = mfma32(tr_frag(dotr, 1, 1, lane), p1, dv1);
+            dk0 = mfma32(tr_frag(qtr, 0, 0, lane), d0, dk0);
+            dk1 = mfma32(tr_frag(qtr, 1, 0, lane), d0, dk1);
+            dk0 = mfma32(tr_frag(qtr, 0, 1, lane), d1, dk0);
+            dk1 = mfma32(tr_frag(qtr, 1, 1, lane), d1, dk1);
+        }
+        if (!last) {
+            char* nb = lds + ((qt + 1) & 1) * BUF;
+            put_row_img(nb, qreg, t);
+            put_tr_img(nb + RIMG, qreg, t);
+            put_row_img(nb + RIMG + TILE_LDS, doreg, t);
+            put_tr_img(nb + 2 * RIMG + TILE_LDS, doreg, t);
+        }
+        __syncthreads();
+    }
+    if (active && key_ok) {
+        store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
+        store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
+    }
+}
+
 // flag dispatch (mask / bias / causal are wave-uniform launch properties)
 #define ATTN_DISPATCH3(KERNEL, grid, s, a, ...)                                                                       \
     do {                                                                                                             \
@@ -649,6 +964,9 @@ bool bf16_layout_ok(const m3ae_attn_desc& d, bool bwd) {
 
 }  // namespace
 
+static int g_attn_coop = getenv("M3AE_ATTN_COOP") ? atoi(getenv("M3AE_ATTN_COOP")) : 1;
+int m3ae_attn_set_coop(int v) { g_attn_coop = v; return 0; }
+
 extern "C" int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward) {
     if (!d) return 0;
     if (d->dtype == M3AE_BF16) return 0;
@@ -665,6 +983,16 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
         if (!bf16_layout_ok(d, false)) return M3AE_ERR_UNSUPPORTED;
         if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
+        if (g_attn_coop) {
+            if (d.Lq > 32 && d.Lk > 64) {
+                dim3 grid((unsigned)cdiv(d.Lq, 256), (unsigned)d.H, (unsigned)d.B);
+                ATTN_DISPATCH3(attn_fwd_coop_kernel, grid, s, a, 2, );
+            } else {
+                dim3 grid((unsigned)cdiv(d.Lq, 128), (unsigned)d.H, (unsigned)d.B);
+                ATTN_DISPATCH3(attn_fwd_coop_kernel, grid, s, a, 1, );
+            }
+            return hip_launch_status();
+        }
         if (d.Lq > 32 && d.Lk > 64) {  // 64 query rows per wave: K / V fragments are fetched once for two query blocks
             dim3 grid((unsigned)cdiv(cdiv(d.Lq, 64), 4), (unsigned)d.H, (unsigned)d.B);
             ATTN_DISPATCH3(attn_fwd_bf16_kernel, grid, s, a, 2, );
@@ -699,9 +1027,14 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         const int64_t total = d.B * d.Lq * d.H;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        ATTN_DISPATCH3(attn_bwd_dq_bf16_kernel, gq, s, a, );
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        ATTN_DISPATCH3(attn_bwd_dkdv_bf16_kernel, gk, s, a, );
+        if (g_attn_coop) {
+            ATTN_DISPATCH3(attn_bwd_dq_coop_kernel, gq, s, a, );
+            ATTN_DISPATCH3(attn_bwd_dkdv_coop_kernel, gk, s, a, );
+        } else {
+            ATTN_DISPATCH3(attn_bwd_dq_bf16_kernel, gq, s, a, );
+            ATTN_DISPATCH3(attn_bwd_dkdv_bf16_kernel, gk, s, a, );
+        }
         return hip_launch_status();
     }
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;

@@ -489,11 +489,13 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+int m3ae_attn_set_coop(int v);
 static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : 2;
 static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
     if (key == 1) { g_tn_variant = value; return 0; }
+    if (key == 2) return m3ae_attn_set_coop(value);
     return M3AE_ERR_ARG;
 }
 

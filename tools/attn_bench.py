@@ -5,7 +5,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mm-vqa-healthcare_amd"))
 import torch  # noqa: E402
-from m3ae_amd import ops  # noqa: E402
+from m3ae_amd import ops, _lib  # noqa: E402
 
 B, H, D = int(os.environ.get("B", 64)), 12, 768
 
@@ -43,6 +43,8 @@ for (Lq, Lk, masked) in [(577, 577, False), (32, 577, False), (577, 32, True), (
     o, lse = ops.attn_forward(q, k, v, H, mask)
     do = torch.randn_like(o)
     fl = 4.0 * B * H * Lq * Lk * 64
-    tf = time_it(lambda: ops.attn_forward(q, k, v, H, mask))
-    tb = time_it(lambda: ops.attn_backward(q, k, v, o, lse, do, dq, dk, dv, H, mask))
-    print(f"attn Lq={Lq:4d} Lk={Lk:4d}: fwd {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | bwd {tb*1e3:8.1f} us {2.5*fl/tb/1e9:7.1f} TF/s", flush=True)
+    for coop in (0, 1):
+        _lib.lib().m3ae_set_tuning(2, coop)
+        tf = time_it(lambda: ops.attn_forward(q, k, v, H, mask))
+        tb = time_it(lambda: ops.attn_backward(q, k, v, o, lse, do, dq, dk, dv, H, mask))
+        print(f"attn coop={coop} Lq={Lq:4d} Lk={Lk:4d}: fwd {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | bwd {tb*1e3:8.1f} us {2.5*fl/tb/1e9:7.1f} TF/s", flush=True)
