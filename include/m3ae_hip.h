@@ -165,6 +165,9 @@ int m3ae_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, 
 
 /* bf16 [R, C] <- fp32 [R, C] cast; and the transposed bf16 copy out_t [C, R] (dgrad operand). either may be NULL */
 int m3ae_cast_transpose(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream);
+/* every weight unit in one launch: jobs_dev = device array of {const float* in; bf16* out_t; int64 R, C, first_tile}
+ * (first_tile = running sum of ceil(R/32)*ceil(C/32)), total_tiles = the final running sum. */
+int m3ae_cast_transpose_batched(const void* jobs_dev, int njobs, int64_t total_tiles, void* stream);
 /* elementwise: out = cast(in) (dtype_in -> dtype_out), n elements */
 int m3ae_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
 /* out = a + b (same dtype) */

@@ -263,6 +263,33 @@ __global__ void cast_transpose_kernel(const float* in, bf16_t* out, bf16_t* out_
         }
     }
 }
+// table-driven form: one launch transposes every GEMM weight unit (desc = {src, dst_t, R, C, first_tile}; tiles are
+// 32 x 32, the unit of a workgroup is found by binary search over first_tile)
+struct TransposeJob { const float* in; bf16_t* out_t; int64_t R, C; int64_t first_tile; };
+__global__ void cast_transpose_batched_kernel(const TransposeJob* jobs, int njobs) {
+    __shared__ float tile[32][33];
+    const int64_t tid = blockIdx.x;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_tile <= tid) lo = mid; else hi = mid - 1;
+    }
+    const TransposeJob j = jobs[lo];
+    const int64_t local = tid - j.first_tile;
+    const int64_t tiles_c = (j.C + 31) / 32;
+    const int64_t c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < j.R && c < j.C) ? j.in[r * j.C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t c = c0 + k, r = r0 + tx;
+        if (r < j.R && c < j.C) j.out_t[c * j.R + r] = f2bf(tile[tx][k]);
+    }
+}
+
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* in, TO* out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -418,6 +445,13 @@ extern "C" int m3ae_cast_transpose(const float* in, void* out, void* out_t, int6
     dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
     if (grid.y > 65535u) return M3AE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, s, in, (bf16_t*)out, (bf16_t*)out_t, R, C);
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_cast_transpose_batched(const void* jobs_dev, int njobs, int64_t total_tiles, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_tiles <= 0) return M3AE_ERR_ARG;
+    hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const TransposeJob*)jobs_dev, njobs);
     return hip_launch_status();
 }
 

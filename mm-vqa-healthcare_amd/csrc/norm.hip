@@ -169,16 +169,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
     }
 }
 
-// fold the per-workgroup partial rows into the fp32 gradients: 32 columns x 8 row-lanes per workgroup
+// fold the per-workgroup partial rows into the fp32 gradients: grid (column blocks of 32, row chunks of 64 partials);
+// 32 columns x 8 row-lanes per workgroup, one fp32 atomic per column per workgroup
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, float* dgamma, float* dbeta, int nblk,
                                                             int D) {
     __shared__ float red[8][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cl;  // index into [2][D]
+    const int b0 = blockIdx.y * 64;
+    const int b1 = b0 + 64 < nblk ? b0 + 64 : nblk;
     float s = 0.f;
     if (i < 2 * D) {
         const int which = i / D, col = i - which * D;
-        for (int b = rl; b < nblk; b += 8) s += part[((int64_t)b * 2 + which) * D + col];
+        for (int b = b0 + rl; b < b1; b += 8) s += part[((int64_t)b * 2 + which) * D + col];
     }
     red[rl][cl] = s;
     __syncthreads();
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, f
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += red[r][cl];
         const int which = i / D, col = i - which * D;
-        if (which == 0) dgamma[col] += t;
-        else if (dbeta) dbeta[col] += t;
+        if (which == 0) atomicAdd(dgamma + col, t);
+        else if (dbeta) atomicAdd(dbeta + col, t);
     }
 }
 
@@ -257,7 +260,7 @@ extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* ga
     rc = run();
     if (rc) return rc;
     if (!dgamma) return 0;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 32)), dim3(256), 0, s, workspace, dgamma,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 32), (unsigned)cdiv(nblk, 64)), dim3(256), 0, s, workspace, dgamma,
                        dbeta, nblk, (int)D);
     return hip_launch_status();
 }

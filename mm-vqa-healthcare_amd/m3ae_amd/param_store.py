@@ -145,6 +145,15 @@ class ParamStore:
                 t = torch.empty((cols, rows), dtype=torch.bfloat16, device=device)
                 u.m3ae_t = t
                 self._t_bufs.append((u, rows, cols, t))
+            # job table for the one-launch transposer
+            import numpy as np
+            tab = np.zeros((len(self._t_bufs), 5), dtype=np.int64)
+            first = 0
+            for i, (u, rows, cols, t) in enumerate(self._t_bufs):
+                tab[i] = (u.data.data_ptr(), t.data_ptr(), rows, cols, first)
+                first += ((rows + 31) // 32) * ((cols + 31) // 32)
+            self._t_tiles = first
+            self._t_jobs = torch.from_numpy(tab).to(device)
         self.sync_shadows()
 
     # ---- shadows -------------------------------------------------------------------------------------------
@@ -159,10 +168,9 @@ class ParamStore:
         if cast:
             _lib.check(L.m3ae_cast(C.c_void_p(self.flat.data_ptr()), C.c_void_p(self.shadow.data_ptr()), self.total,
                                    _lib.F32, _lib.BF16, s), "m3ae_cast")
-        for u, rows, cols, t in self._t_bufs:
-            src = u.data
-            _lib.check(L.m3ae_cast_transpose(C.c_void_p(src.data_ptr()), None, C.c_void_p(t.data_ptr()), rows, cols, s),
-                       "m3ae_cast_transpose")
+        if self._t_bufs:
+            _lib.check(L.m3ae_cast_transpose_batched(C.c_void_p(self._t_jobs.data_ptr()), len(self._t_bufs),
+                                                     self._t_tiles, s), "m3ae_cast_transpose_batched")
 
     # ---- optimizer -----------------------------------------------------------------------------------------
     def zero_grad(self):
