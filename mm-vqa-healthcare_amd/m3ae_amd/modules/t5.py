@@ -1,0 +1,212 @@
+"""T5 encoder-decoder for the generative answer head on the MI355X kernels.
+
+The reference uses HF `T5ForConditionalGeneration` (third party, transformers==4.6.0) through
+m3ae/modules/m3ae_t5_mm_encoder_input.py:26-27,202,244.  This module keeps HF's parameter names
+(`shared.weight`, `encoder.block.{i}.layer.0.SelfAttention.{q,k,v,o}.weight`, `...relative_attention_bias.weight`,
+`layer.{j}.layer_norm.weight`, `DenseReluDense.{wi,wo}.weight`, `decoder.block.{i}.layer.1.EncDecAttention...`,
+`final_layer_norm.weight`) so `t5.*` checkpoints load by name, and runs each pre-norm block as one fused autograd
+node (ops.T5EncBlockFn / ops.T5DecBlockFn): RMSNorm -> packed QKV GEMM -> attention with the additive relative
+position bias (no 1/sqrt(d) scaling) -> output GEMM (+residual) -> RMSNorm -> GEMM(+ReLU) -> GEMM(+residual).
+The LM head is tied to `shared` and the decoder output is scaled by d_model^-0.5 (T5 v1.0 / t5-small, t5-base).
+"""
+import math
+from types import SimpleNamespace as NS
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..param_store import PackedParam
+
+T5_ARCH = {
+    "t5-small": dict(d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_decoder_layers=6, num_heads=8),
+    "t5-base": dict(d_model=768, d_kv=64, d_ff=3072, num_layers=12, num_decoder_layers=12, num_heads=12),
+    "t5-large": dict(d_model=1024, d_kv=64, d_ff=4096, num_layers=24, num_decoder_layers=24, num_heads=16),
+}
+
+
+class T5LayerNorm(nn.Module):
+    def __init__(self, d, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = None
+        self.eps = eps
+
+
+class T5Attention(nn.Module):
+    def __init__(self, d_model, heads, d_kv, has_bias, is_decoder, buckets=32, max_distance=128):
+        super().__init__()
+        inner = heads * d_kv
+        self.heads, self.is_decoder, self.buckets, self.max_distance = heads, is_decoder, buckets, max_distance
+        self.q = nn.Linear(d_model, inner, bias=False)
+        self.k = nn.Linear(d_model, inner, bias=False)
+        self.v = nn.Linear(d_model, inner, bias=False)
+        self.o = nn.Linear(inner, d_model, bias=False)
+        if has_bias:
+            self.relative_attention_bias = nn.Embedding(buckets, heads)
+        self._packs = {}
+
+    def pack(self, kind):
+        if kind not in self._packs:
+            mods = {"qkv": (self.q, self.k, self.v), "kv": (self.k, self.v)}[kind]
+            self._packs[kind] = PackedParam([m.weight for m in mods])
+        return self._packs[kind]
+
+    def bucket(self, Lq, Lk, device):
+        """T5Attention._relative_position_bucket (integer glue, host-side shapes)."""
+        ctx = torch.arange(Lq, device=device)[:, None]
+        mem = torch.arange(Lk, device=device)[None, :]
+        rel = mem - ctx
+        nb = self.buckets
+        ret = torch.zeros_like(rel)
+        if not self.is_decoder:
+            nb //= 2
+            ret = ret + (rel > 0).long() * nb
+            rel = rel.abs()
+        else:
+            rel = -torch.min(rel, torch.zeros_like(rel))
+        max_exact = nb // 2
+        is_small = rel < max_exact
+        large = max_exact + (torch.log(rel.float() / max_exact) / math.log(self.max_distance / max_exact)
+                             * (nb - max_exact)).long()
+        large = torch.min(large, torch.full_like(large, nb - 1))
+        return ret + torch.where(is_small, rel, large)
+
+    def position_bias(self, Lq, Lk):
+        """compute_bias: fp32 [H, Lq, Lk]; differentiable in the (tiny) bucket table through autograd glue."""
+        w = self.relative_attention_bias.weight
+        return w[self.bucket(Lq, Lk, w.device)].permute(2, 0, 1).contiguous().float()
+
+
+class _SelfAttnLayer(nn.Module):
+    def __init__(self, d_model, heads, d_kv, has_bias, is_decoder):
+        super().__init__()
+        self.SelfAttention = T5Attention(d_model, heads, d_kv, has_bias, is_decoder)
+        self.layer_norm = T5LayerNorm(d_model)
+
+
+class _CrossAttnLayer(nn.Module):
+    def __init__(self, d_model, heads, d_kv):
+        super().__init__()
+        self.EncDecAttention = T5Attention(d_model, heads, d_kv, False, True)
+        self.layer_norm = T5LayerNorm(d_model)
+
+
+class _DenseReluDense(nn.Module):
+    def __init__(self, d_model, d_ff):
+        super().__init__()
+        self.wi = nn.Linear(d_model, d_ff, bias=False)
+        self.wo = nn.Linear(d_ff, d_model, bias=False)
+
+
+class _FFLayer(nn.Module):
+    def __init__(self, d_model, d_ff):
+        super().__init__()
+        self.DenseReluDense = _DenseReluDense(d_model, d_ff)
+        self.layer_norm = T5LayerNorm(d_model)
+
+
+def _attn_params(att, ln, cross):
+    if cross:
+        return NS(heads=att.heads, w_q=att.q.weight, w_kv=att.pack("kv"), w_o=att.o.weight, ln=ln)
+    return NS(heads=att.heads, w_qkv=att.pack("qkv"), w_o=att.o.weight, ln=ln)
+
+
+class T5Block(nn.Module):
+    def __init__(self, d_model, heads, d_kv, d_ff, has_bias, is_decoder):
+        super().__init__()
+        self.is_decoder = is_decoder
+        layers = [_SelfAttnLayer(d_model, heads, d_kv, has_bias, is_decoder)]
+        if is_decoder:
+            layers.append(_CrossAttnLayer(d_model, heads, d_kv))
+        layers.append(_FFLayer(d_model, d_ff))
+        self.layer = nn.ModuleList(layers)
+        self._bp = None
+
+    def params(self):
+        if self._bp is None:
+            sa = self.layer[0]
+            ff = self.layer[-1]
+            self._bp = NS(attn=_attn_params(sa.SelfAttention, sa.layer_norm, False),
+                          ffn=NS(w1=ff.DenseReluDense.wi.weight, w2=ff.DenseReluDense.wo.weight, ln=ff.layer_norm))
+            if self.is_decoder:
+                ca = self.layer[1]
+                self._bp.cross = _attn_params(ca.EncDecAttention, ca.layer_norm, True)
+            self._anchors = tuple(self.parameters())
+        return self._bp
+
+    def forward(self, h, pos_bias, enc=None):
+        P = self.params()
+        if self.is_decoder:
+            return ops.T5DecBlockFn.apply(h, enc, pos_bias, P, *self._anchors)
+        return ops.T5EncBlockFn.apply(h, pos_bias, P, *self._anchors)
+
+    def weight_units(self):
+        sa = self.layer[0].SelfAttention
+        ff = self.layer[-1].DenseReluDense
+        u = [sa.pack("qkv"), sa.o.weight, ff.wi.weight, ff.wo.weight]
+        if self.is_decoder:
+            ca = self.layer[1].EncDecAttention
+            u += [ca.q.weight, ca.pack("kv"), ca.o.weight]
+        return u
+
+
+class T5Stack(nn.Module):
+    def __init__(self, n_layers, d_model, heads, d_kv, d_ff, is_decoder):
+        super().__init__()
+        self.is_decoder = is_decoder
+        self.block = nn.ModuleList([T5Block(d_model, heads, d_kv, d_ff, i == 0, is_decoder) for i in range(n_layers)])
+        self.final_layer_norm = T5LayerNorm(d_model)
+
+    def forward(self, h, enc=None):
+        L = h.shape[1]
+        bias = self.block[0].layer[0].SelfAttention.position_bias(L, L)
+        for blk in self.block:
+            h = blk(h, bias, enc)
+        ln = self.final_layer_norm
+        return ops.layer_norm(h, ln.weight, None, ln.eps, rms=True)
+
+    def weight_units(self):
+        u = []
+        for b in self.block:
+            u += b.weight_units()
+        return u
+
+
+class T5ForConditionalGeneration(nn.Module):
+    """Encoder + teacher-forced decoder + tied LM head + cross-entropy (HF T5ForConditionalGeneration.forward with
+    `encoder_outputs` / `inputs_embeds` and `labels`).  Generation (beam search) is not on the training hot path and is
+    not provided."""
+
+    def __init__(self, name_or_dims="t5-small", vocab_size=32128):
+        super().__init__()
+        dims = T5_ARCH[name_or_dims] if isinstance(name_or_dims, str) else dict(name_or_dims)
+        self.config = NS(hidden_size=dims["d_model"], d_model=dims["d_model"], vocab_size=vocab_size,
+                         num_heads=dims["num_heads"], pad_token_id=0, decoder_start_token_id=0, eos_token_id=1)
+        d = dims["d_model"]
+        self.shared = nn.Embedding(vocab_size, d)
+        self.encoder = T5Stack(dims["num_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], False)
+        self.decoder = T5Stack(dims["num_decoder_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], True)
+
+    def weight_units(self):
+        return [self.shared.weight] + self.encoder.weight_units() + self.decoder.weight_units()
+
+    def shift_right(self, labels):
+        out = torch.zeros_like(labels)
+        out[:, 1:] = labels[:, :-1]
+        out[:, 0] = self.config.decoder_start_token_id
+        return out.masked_fill(out == -100, self.config.pad_token_id)
+
+    def embed(self, ids, dtype):
+        w = self.shared.weight
+        table = ops.compute_weight(w) if dtype == torch.bfloat16 else w
+        B, T = ids.shape
+        return ops.EmbedRowsFn.apply(ids.reshape(-1), w, table).view(B, T, -1)
+
+    def forward(self, inputs_embeds, labels):
+        enc = self.encoder(inputs_embeds)
+        dec_in = self.embed(self.shift_right(labels), inputs_embeds.dtype)
+        dec = self.decoder(dec_in, enc)
+        logits = ops.linear(dec, self.shared.weight, None, alpha=self.config.d_model ** -0.5)
+        loss = ops.cross_entropy(logits, labels)
+        return NS(loss=loss, logits=logits, encoder_last_hidden_state=enc)

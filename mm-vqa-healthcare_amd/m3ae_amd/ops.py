@@ -112,33 +112,35 @@ def _rows(x):
 
 
 def mm_nt(x2, ldx, M, w, bias=None, act=ACT_NONE, residual=None, want_preact=False, out_dtype=None, dact_aux=None,
-          dact=ACT_NONE, force_generic=False):
-    """y[M,N] = epi(x2[M,K] . w[N,K]^T)."""
+          dact=ACT_NONE, force_generic=False, alpha=1.0):
+    """y[M,N] = epi(alpha * x2[M,K] . w[N,K]^T)."""
     N, K = w.shape
     y = torch.empty((M, N), dtype=out_dtype or x2.dtype, device=x2.device)
     pre = torch.empty_like(y) if want_preact else None
     gemm(x2, ldx, 1, w, 1, w.stride(0), y, N, M, N, K, bias=bias, act=act, preact=pre, residual=residual,
-         dact_aux=dact_aux, dact=dact, force_generic=force_generic)
+         dact_aux=dact_aux, dact=dact, force_generic=force_generic, alpha=alpha)
     return y, pre
 
 
-def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None):
+def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None, alpha=1.0):
     """dx[M,K] = dy[M,N] . W[N,K]  (bf16: NT against the transposed shadow; fp32: strided generic)."""
     M, N = dy.shape
     wt = getattr(w_param, "m3ae_t", None)
     if wt is not None:
         K = wt.shape[0]
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
-        gemm(dy, dy.stride(0), 1, wt, 1, wt.stride(0), dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual)
+        gemm(dy, dy.stride(0), 1, wt, 1, wt.stride(0), dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual,
+             alpha=alpha)
     else:
         w = compute_weight(w_param)
         K = w.shape[1]
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
-        gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual)
+        gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual,
+             alpha=alpha)
     return dx
 
 
-def mm_wgrad(dy, x2, ldx, w_param, b_param=None):
+def mm_wgrad(dy, x2, ldx, w_param, b_param=None, alpha=1.0):
     """w.grad[N,K] += dy[M,N]^T . x2[M,K]  (fp32 accumulate in place); with b_param also b.grad[N] += colsum(dy),
     fused into the same kernel (row sums of the A operand dy^T)."""
     want_b = b_param is not None and b_param.requires_grad
@@ -149,7 +151,7 @@ def mm_wgrad(dy, x2, ldx, w_param, b_param=None):
     g = _grad_buf(w_param)
     M, N = dy.shape
     K = g.shape[1]
-    gemm(dy, 1, dy.stride(0), x2, ldx, 1, g, g.stride(0), N, K, M, accumulate=True,
+    gemm(dy, 1, dy.stride(0), x2, ldx, 1, g, g.stride(0), N, K, M, accumulate=True, alpha=alpha,
          a_rowsum=_grad_buf(b_param) if want_b else None)
     _done(w_param)
     if want_b:
@@ -201,7 +203,7 @@ class LinearFn(torch.autograd.Function):
     PackedParam (graph recording only)."""
 
     @staticmethod
-    def forward(ctx, x, residual, extra_bias, weight, bias, act, *anchors):
+    def forward(ctx, x, residual, extra_bias, weight, bias, act, alpha, *anchors):
         x2, M, K, ldx = _rows(x)
         w = compute_weight(weight)
         b = None if bias is None else (bias.data if hasattr(bias, "members") else bias.detach())
@@ -210,9 +212,9 @@ class LinearFn(torch.autograd.Function):
         res2 = None
         if residual is not None:
             res2 = residual.contiguous().view(M, -1)
-        y, pre = mm_nt(x2, ldx, M, w, bias=b, act=act, residual=res2, want_preact=(act != ACT_NONE))
+        y, pre = mm_nt(x2, ldx, M, w, bias=b, act=act, residual=res2, want_preact=(act != ACT_NONE), alpha=alpha)
         ctx.save_for_backward(x2, pre)
-        ctx.weight, ctx.bias, ctx.act, ctx.ldx = weight, bias, act, ldx
+        ctx.weight, ctx.bias, ctx.act, ctx.ldx, ctx.alpha = weight, bias, act, ldx, alpha
         ctx.x_shape, ctx.has_res = x.shape, residual is not None
         ctx.x_needs = x.requires_grad
         ctx.extra_needs = extra_bias is not None and extra_bias.requires_grad
@@ -228,7 +230,7 @@ class LinearFn(torch.autograd.Function):
         dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
         dextra = None
         if ctx.extra_needs:
-            mm_wgrad(dz, x2, ctx.ldx, ctx.weight)
+            mm_wgrad(dz, x2, ctx.ldx, ctx.weight, alpha=ctx.alpha)
             dextra = torch.empty(N, dtype=torch.float32, device=dz.device)
             check(_lib.lib().m3ae_colsum(_p(dz), _p(dextra), dz.shape[0], N, dz.stride(0), _dt(dz), 0, _stream()),
                   "m3ae_colsum")
@@ -236,11 +238,11 @@ class LinearFn(torch.autograd.Function):
                 _grad_buf(ctx.bias).add_(dextra)
                 _done(ctx.bias)
         else:
-            mm_wgrad(dz, x2, ctx.ldx, ctx.weight, ctx.bias)
+            mm_wgrad(dz, x2, ctx.ldx, ctx.weight, ctx.bias, alpha=ctx.alpha)
         dx = None
         if ctx.x_needs:
-            dx = mm_dgrad(dz, ctx.weight).view(ctx.x_shape)
-        return (dx, dres, dextra, None, None, None) + (None,) * ctx.n_anchor
+            dx = mm_dgrad(dz, ctx.weight, alpha=ctx.alpha).view(ctx.x_shape)
+        return (dx, dres, dextra, None, None, None, None) + (None,) * ctx.n_anchor
 
 
 class GatherLinearFn(torch.autograd.Function):
@@ -303,11 +305,11 @@ class MLPFn(torch.autograd.Function):
         return dx, dres, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, residual=None, extra_bias=None):
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, extra_bias=None, alpha=1.0):
     anchors = tuple(_members(weight)) if hasattr(weight, "members") else ()
     if hasattr(bias, "members"):
         anchors = anchors + tuple(bias.members)
-    return LinearFn.apply(x, residual, extra_bias, weight, bias, act, *anchors)
+    return LinearFn.apply(x, residual, extra_bias, weight, bias, act, alpha, *anchors)
 
 
 def mlp(x, w1, b1, w2, b2, act, residual=None):
@@ -359,17 +361,17 @@ def layer_norm(x, gamma, beta, eps, act=ACT_NONE, rms=False):
 # ----------------------------------------------------------------------------------------------------------
 # raw LayerNorm helpers (no autograd) for the fused block functions
 # ----------------------------------------------------------------------------------------------------------
-def ln_fwd_raw(x2, ln, act=ACT_NONE):
+def ln_fwd_raw(x2, ln, act=ACT_NONE, rms=False):
     M, D = x2.shape
     y = torch.empty_like(x2)
-    mean = torch.empty(M, dtype=torch.float32, device=x2.device)
+    mean = None if rms else torch.empty(M, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x2.device)
     check(_lib.lib().m3ae_layernorm_fwd(_p(x2), _p(ln.weight), _p(ln.bias), _p(y), _p(mean), _p(rstd), M, D, ln.eps,
-                                        _dt(x2), act, 0, _stream()), "m3ae_layernorm_fwd")
+                                        _dt(x2), act, int(rms), _stream()), "m3ae_layernorm_fwd")
     return y, mean, rstd
 
 
-def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE):
+def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE, rms=False):
     """dx = LN'(dy) (+ dx_add); ln.weight.grad / ln.bias.grad accumulate in place."""
     M, D = x2.shape
     L = _lib.lib()
@@ -380,7 +382,7 @@ def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE):
     gg = _grad_buf(ln.weight) if train else None
     gb = _grad_buf(ln.bias) if (train and ln.bias is not None) else None
     check(L.m3ae_layernorm_bwd(_p(dy), _p(x2), _p(ln.weight), _p(ln.bias), _p(mean), _p(rstd), _p(dx), _p(dx_add),
-                               _p(gg), _p(gb), _p(ws), M, D, _dt(x2), act, 0, _stream()), "m3ae_layernorm_bwd")
+                               _p(gg), _p(gb), _p(ws), M, D, _dt(x2), act, int(rms), _stream()), "m3ae_layernorm_bwd")
     if train:
         _done(ln.weight)
         _done(ln.bias)
@@ -681,6 +683,161 @@ class ClipBlockFn(torch.autograd.Function):
         dh1 = mm_dgrad(dqkv, P.w_in)
         dx = ln_bwd_raw(dh1, x2, P.ln1, m1, r1, dx_add=dxa)
         return (dx.view(B, L, D), None) + (None,) * ctx.n_anchor
+
+
+# ----------------------------------------------------------------------------------------------------------
+# T5 pre-norm blocks (HF T5Block restated; m3ae_t5_mm_encoder_input.py:202,244): RMSNorm, no linear biases, no
+# 1/sqrt(d) scaling, additive relative-position bias, ReLU FFN.  One autograd node per block.
+# ----------------------------------------------------------------------------------------------------------
+def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal):
+    n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
+    D = n.shape[1]
+    inner = P.w_o.shape[1]
+    if src2 is None:
+        qkv, _ = mm_nt(n, D, B * L, compute_weight(P.w_qkv))
+        v3 = qkv.view(B, L, 3 * inner)
+        o, lse = attn_forward(v3[..., :inner], v3[..., inner:2 * inner], v3[..., 2 * inner:], P.heads, None, bias,
+                              scale=1.0, causal=causal)
+        proj = (qkv,)
+    else:
+        q, _ = mm_nt(n, D, B * L, compute_weight(P.w_q))
+        kv, _ = mm_nt(src2, src2.shape[1], B * Ls, compute_weight(P.w_kv))
+        kv3 = kv.view(B, Ls, 2 * inner)
+        o, lse = attn_forward(q.view(B, L, inner), kv3[..., :inner], kv3[..., inner:], P.heads, None, bias, scale=1.0,
+                              causal=causal)
+        proj = (q, kv)
+    y, _ = mm_nt(o.view(B * L, inner), inner, B * L, compute_weight(P.w_o), residual=h2)
+    return y, (h2, rstd, n, proj, o, lse, src2)
+
+
+def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need_dsrc=True):
+    h2, rstd, n, proj, o, lse, src2 = saved
+    need_dh = need_dh or P.ln.weight.requires_grad  # the RMSNorm scale gradient comes out of the same kernel
+    D = n.shape[1]
+    inner = P.w_o.shape[1]
+    mm_wgrad(dy, o.view(B * L, inner), inner, P.w_o)
+    dctx = mm_dgrad(dy, P.w_o).view(B, L, inner)
+    dsrc = None
+    if src2 is None:
+        (qkv,) = proj
+        v3 = qkv.view(B, L, 3 * inner)
+        dqkv = torch.empty_like(qkv)
+        d3 = dqkv.view(B, L, 3 * inner)
+        attn_backward(v3[..., :inner], v3[..., inner:2 * inner], v3[..., 2 * inner:], o, lse, dctx, d3[..., :inner],
+                      d3[..., inner:2 * inner], d3[..., 2 * inner:], P.heads, None, bias, scale=1.0, causal=causal,
+                      d_pos_bias=dbias)
+        mm_wgrad(dqkv, n, D, P.w_qkv)
+        dn = mm_dgrad(dqkv, P.w_qkv) if need_dh else None
+    else:
+        q, kv = proj
+        kv3 = kv.view(B, Ls, 2 * inner)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dkv3 = dkv.view(B, Ls, 2 * inner)
+        attn_backward(q.view(B, L, inner), kv3[..., :inner], kv3[..., inner:], o, lse, dctx, dq.view(B, L, inner),
+                      dkv3[..., :inner], dkv3[..., inner:], P.heads, None, bias, scale=1.0, causal=causal,
+                      d_pos_bias=dbias)
+        mm_wgrad(dq, n, D, P.w_q)
+        mm_wgrad(dkv, src2, src2.shape[1], P.w_kv)
+        dn = mm_dgrad(dq, P.w_q) if need_dh else None
+        dsrc = mm_dgrad(dkv, P.w_kv) if need_dsrc else None
+    dh = ln_bwd_raw(dn, h2, P.ln, None, rstd, dx_add=dy, rms=True) if need_dh else None
+    return dh, dsrc
+
+
+def _t5_ff_fwd(h2, P):
+    n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
+    M, D = n.shape
+    g, u = mm_nt(n, D, M, compute_weight(P.w1), act=ACT_RELU, want_preact=True)
+    y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), residual=h2)
+    return y, (h2, rstd, n, u, g)
+
+
+def _t5_ff_bwd(dy, saved, P):
+    h2, rstd, n, u, g = saved
+    mm_wgrad(dy, g, g.shape[1], P.w2)
+    du = mm_dgrad(dy, P.w2, dact_aux=u, dact=ACT_RELU)
+    mm_wgrad(du, n, n.shape[1], P.w1)
+    dn = mm_dgrad(du, P.w1)
+    return ln_bwd_raw(dn, h2, P.ln, None, rstd, dx_add=dy, rms=True)
+
+
+class T5EncBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, pos_bias, P, *anchors):
+        B, L, D = h.shape
+        h2 = h.contiguous().view(B * L, D)
+        bias = pos_bias.detach() if pos_bias is not None else None
+        a, s1 = _t5_attn_fwd(h2, B, L, None, L, P.attn, bias, False)
+        y, s2 = _t5_ff_fwd(a, P.ffn)
+        ctx.saved = (s1, s2, bias)
+        ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
+        ctx.need_h = h.requires_grad
+        ctx.need_bias = pos_bias is not None and pos_bias.requires_grad
+        return y.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, D = ctx.dims
+        s1, s2, bias = ctx.saved
+        ctx.saved = None
+        dbias = torch.zeros_like(bias) if ctx.need_bias else None
+        da = _t5_ff_bwd(dy.contiguous().view(B * L, D), s2, ctx.P.ffn)
+        dh, _ = _t5_attn_bwd(da, s1, B, L, L, ctx.P.attn, bias, False, dbias, need_dh=ctx.need_h)
+        return (None if dh is None else dh.view(B, L, D), dbias, None) + (None,) * ctx.n_anchor
+
+
+class T5DecBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, enc, pos_bias, P, *anchors):
+        B, T, D = h.shape
+        Ls = enc.shape[1]
+        h2 = h.contiguous().view(B * T, D)
+        enc2 = enc.contiguous().view(B * Ls, enc.shape[2])
+        bias = pos_bias.detach() if pos_bias is not None else None
+        a, s1 = _t5_attn_fwd(h2, B, T, None, T, P.attn, bias, True)
+        c, s2 = _t5_attn_fwd(a, B, T, enc2, Ls, P.cross, None, False)
+        y, s3 = _t5_ff_fwd(c, P.ffn)
+        ctx.saved = (s1, s2, s3, bias)
+        ctx.P, ctx.dims, ctx.n_anchor = P, (B, T, Ls, D), len(anchors)
+        ctx.need_h, ctx.need_enc = h.requires_grad, enc.requires_grad
+        ctx.need_bias = pos_bias is not None and pos_bias.requires_grad
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, Ls, D = ctx.dims
+        s1, s2, s3, bias = ctx.saved
+        ctx.saved = None
+        P = ctx.P
+        dbias = torch.zeros_like(bias) if ctx.need_bias else None
+        dc = _t5_ff_bwd(dy.contiguous().view(B * T, D), s3, P.ffn)
+        da, denc = _t5_attn_bwd(dc, s2, B, T, Ls, P.cross, None, False, None, need_dsrc=ctx.need_enc)
+        dh, _ = _t5_attn_bwd(da, s1, B, T, T, P.attn, bias, True, dbias, need_dh=ctx.need_h)
+        return (None if dh is None else dh.view(B, T, D), None if denc is None else denc.view(B, Ls, -1), dbias,
+                None) + (None,) * ctx.n_anchor
+
+
+class EmbedRowsFn(torch.autograd.Function):
+    """rows = table[ids] (T5 `shared` lookup for the teacher-forced decoder input).  `table` is the compute-dtype
+    view of `weight`; the gradient (only when the embedding is trainable) is scatter-added into weight.grad."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, table):
+        out = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+        check(_lib.lib().m3ae_gather_rows(_p(table), _p(ids), _p(out), ids.numel(), table.shape[1], _dt(table),
+                                          _stream()), "m3ae_gather_rows")
+        ctx.save_for_backward(ids)
+        ctx.weight = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        if ctx.weight.requires_grad:  # rare path: the embedding is frozen in the reference's recipe
+            _grad_buf(ctx.weight).index_add_(0, ids, dout.float())
+            _done(ctx.weight)
+        return None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -90,17 +90,32 @@ class PackedParam:
         return None if g0 is None else self._view(g0)
 
 
+def param_group_of_decoder(name):
+    """The two groups of m3ae_t5_utils.set_schedule_decoder (:308-333): no-decay by substring, one learning rate."""
+    nd = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight"]
+    return 1 if any(k in name for k in nd) else 0
+
+
+def group_hparams_decoder(cfg):
+    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    return [(lr, wd), (lr, 0.0)] + [(lr, 0.0)] * 4
+
+
 class ParamStore:
-    def __init__(self, module, cfg, device, compute_dtype=torch.bfloat16, weight_units=None, frozen=()):
+    def __init__(self, module, cfg, device, compute_dtype=torch.bfloat16, weight_units=None, frozen=(),
+                 group_fn=param_group_of, hparams_fn=group_hparams):
         self.module, self.cfg, self.device, self.compute_dtype = module, cfg, device, compute_dtype
+        self.hparams_fn = hparams_fn
         named = [(n, p) for n, p in module.named_parameters()]
         self.names = {id(p): n for n, p in named}
-        groups = [[] for _ in range(7)]  # 0..5 optimizer groups, 6 = no-grad
+        # 0..5 optimizer groups; 6..11 = the same classes for parameters without gradient (frozen / never used), kept
+        # apart so that weights stay adjacent to weights and biases to biases (PackedParam views) there too
+        groups = [[] for _ in range(12)]
         for n, p in named:
-            gi = param_group_of(n)
+            gi = group_fn(n)
             unused = any(n == u or n.endswith("." + u) for u in NEVER_USED) or any(n.startswith(f) for f in frozen)
             if unused or gi < 0 or not p.requires_grad:
-                groups[6].append((n, p))
+                groups[6 + max(gi, 0)].append((n, p))
             else:
                 groups[gi].append((n, p))
         self.groups = groups
@@ -203,7 +218,7 @@ class ParamStore:
         self.step_count += 1
         L = _lib.lib()
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for gi, (lr, wd) in enumerate(group_hparams(self.cfg)):
+        for gi, (lr, wd) in enumerate(self.hparams_fn(self.cfg)):
             a, b = self.segments[gi]
             if b <= a:
                 continue

@@ -371,3 +371,126 @@ def adamw_step(p, g, m, v, step, lr, wd, beta1=0.9, beta2=0.98, eps=1e-8):
     if wd > 0:
         p.add_(p, alpha=-lr * wd)
     return p
+
+
+# ------------------------------------------------------------------------------------------------
+# T5 generative head (m3ae_t5_mm_encoder_input.py:100-295; T5 arithmetic = third-party HF
+# T5ForConditionalGeneration, transformers==4.6.0, restated from the container's implementation)
+# ------------------------------------------------------------------------------------------------
+def t5_rmsnorm(sd, key, x, eps=1e-6):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * weight (no mean subtraction, no bias)."""
+    var = x.pow(2).mean(-1, keepdim=True)
+    return x * torch.rsqrt(var + eps) * sd[key]
+
+
+def t5_rel_bucket(rel, bidirectional, num_buckets=32, max_distance=128):
+    """T5Attention._relative_position_bucket."""
+    ret = torch.zeros_like(rel)
+    if bidirectional:
+        num_buckets //= 2
+        ret = ret + (rel > 0).long() * num_buckets
+        rel = rel.abs()
+    else:
+        rel = -torch.min(rel, torch.zeros_like(rel))
+    max_exact = num_buckets // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (num_buckets - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return ret + torch.where(is_small, rel, large)
+
+
+def t5_position_bias(table, Lq, Lk, bidirectional):
+    """T5Attention.compute_bias -> [H, Lq, Lk]."""
+    ctx = torch.arange(Lq)[:, None]
+    mem = torch.arange(Lk)[None, :]
+    bucket = t5_rel_bucket(mem - ctx, bidirectional)
+    return table[bucket].permute(2, 0, 1)
+
+
+def t5_attention(sd, prefix, x, kv, bias, heads):
+    """T5Attention.forward: no 1/sqrt(d) scaling, additive position bias (+ mask), no linear biases."""
+    q = split_heads(x @ sd[prefix + ".q.weight"].t(), heads)
+    k = split_heads(kv @ sd[prefix + ".k.weight"].t(), heads)
+    v = split_heads(kv @ sd[prefix + ".v.weight"].t(), heads)
+    s = q @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    p = torch.softmax(s.float(), dim=-1)
+    return merge_heads(p @ v) @ sd[prefix + ".o.weight"].t()
+
+
+def t5_ff(sd, prefix, x):
+    """T5DenseActDense (feed_forward_proj = relu): wo(relu(wi(x)))."""
+    return torch.relu(x @ sd[prefix + ".wi.weight"].t()) @ sd[prefix + ".wo.weight"].t()
+
+
+def t5_encoder(sd, embeds, heads, prefix="t5.encoder"):
+    """T5Stack (encoder), all-ones attention mask (m3ae_t5_mm_encoder_input.py:174-178,202)."""
+    L = embeds.shape[1]
+    bias = t5_position_bias(sd[f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], L, L, True)
+    h = embeds
+    i = 0
+    while f"{prefix}.block.{i}.layer.0.SelfAttention.q.weight" in sd:
+        b = f"{prefix}.block.{i}"
+        h = h + t5_attention(sd, b + ".layer.0.SelfAttention", t5_rmsnorm(sd, b + ".layer.0.layer_norm.weight", h),
+                             t5_rmsnorm(sd, b + ".layer.0.layer_norm.weight", h), bias[None], heads)
+        h = h + t5_ff(sd, b + ".layer.1.DenseReluDense", t5_rmsnorm(sd, b + ".layer.1.layer_norm.weight", h))
+        i += 1
+    return t5_rmsnorm(sd, prefix + ".final_layer_norm.weight", h)
+
+
+def t5_decoder(sd, dec_ids, enc_out, heads, prefix="t5.decoder"):
+    """T5Stack (decoder), teacher forced: causal self-attention with unidirectional relative bias, cross-attention
+    over the encoder output (zero position bias, all-ones encoder mask)."""
+    T = dec_ids.shape[1]
+    h = sd["t5.shared.weight"][dec_ids]
+    bias = t5_position_bias(sd[f"{prefix}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False)
+    causal = torch.full((T, T), float("-inf")).triu(1)
+    sbias = (bias + causal)[None]
+    i = 0
+    while f"{prefix}.block.{i}.layer.0.SelfAttention.q.weight" in sd:
+        b = f"{prefix}.block.{i}"
+        n = t5_rmsnorm(sd, b + ".layer.0.layer_norm.weight", h)
+        h = h + t5_attention(sd, b + ".layer.0.SelfAttention", n, n, sbias, heads)
+        n = t5_rmsnorm(sd, b + ".layer.1.layer_norm.weight", h)
+        h = h + t5_attention(sd, b + ".layer.1.EncDecAttention", n, enc_out, None, heads)
+        h = h + t5_ff(sd, b + ".layer.2.DenseReluDense", t5_rmsnorm(sd, b + ".layer.2.layer_norm.weight", h))
+        i += 1
+    return t5_rmsnorm(sd, prefix + ".final_layer_norm.weight", h)
+
+
+def t5_shift_right(labels, start_id=0, pad_id=0):
+    """T5ForConditionalGeneration._shift_right."""
+    out = torch.zeros_like(labels)
+    out[:, 1:] = labels[:, :-1]
+    out[:, 0] = start_id
+    return out.masked_fill(out == -100, pad_id)
+
+
+def t5_head_inputs(sd, cls_feats, prefix_ids, proj_w, proj_b, max_len=512):
+    """prepare_inputs (m3ae_t5_mm_encoder_input.py:100-190) with include_cls_feats=True, include_imagetext_feats=False:
+    per sample [shared[prefix_ids] ; Linear(1536->512)(cls)] zero-padded to 512 rows.  The reference draws a FRESH
+    random nn.Linear per sample per call (:75-77,128-129); here it is an explicit (proj_w, proj_b) -- documented
+    deviation, see DESIGN.md."""
+    B = cls_feats.shape[0]
+    d = sd["t5.shared.weight"].shape[1]
+    pre = sd["t5.shared.weight"][prefix_ids]                    # [P, d]
+    proj = cls_feats @ proj_w.t() + proj_b                      # [B, d]
+    x = torch.zeros(B, max_len, d)
+    P = pre.shape[0]
+    x[:, :P] = pre
+    x[:, P] = proj
+    return x
+
+
+def t5_loss(sd, enc_in, labels, heads):
+    """forward (m3ae_t5_mm_encoder_input.py:202,244): encoder -> teacher-forced decoder -> tied LM head (decoder
+    output scaled by d_model^-0.5) -> CrossEntropy(ignore_index=-100) over ALL label positions (pad id 0 included,
+    as the reference passes tokenizer output unmasked)."""
+    enc = t5_encoder(sd, enc_in, heads)
+    dec = t5_decoder(sd, t5_shift_right(labels), enc, heads)
+    d = dec.shape[-1]
+    logits = (dec * d ** -0.5) @ sd["t5.shared.weight"].t()
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100)
+    return loss, logits

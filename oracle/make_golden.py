@@ -190,13 +190,103 @@ def run_pretrain():
     print("[pretrain] mlm", res["mlm_loss"], "mim", res["mim_loss"], "itm", res["itm_loss"])
 
 
+def run_t5():
+    """configs[2] path on a tiny model: the reference's T5VQA_MMEncoderInput (m3ae_t5_mm_encoder_input.py) with
+    random-init HF T5 (d_model 512 is hard-wired in the reference's prepare_inputs), 2+2 layers, deterministic
+    weights, a fixed (instead of per-call random) CLS projection, unfreeze_top_layers(4, 4) as main_t5_m3ae.py:30."""
+    rs.install()
+    import types
+    import torch.nn as nn
+    from transformers import T5Config, T5ForConditionalGeneration
+    import m3ae.modules.m3ae_t5_mm_encoder_input as tm
+    import m3ae.modules.m3ae_t5_utils as tu
+
+    VOC = 1100
+
+    class Tok:
+        pad_token_id, eos_token_id = 0, 1
+
+        @staticmethod
+        def from_pretrained(*a, **k):
+            return Tok()
+
+        def __call__(self, text, **k):
+            if isinstance(text, str):
+                assert text == "question:"
+                return types.SimpleNamespace(input_ids=torch.tensor([[822, 10]]))
+            rows = [[int(t) for t in s.split()] + [1] for s in text]
+            T = max(len(r) for r in rows)
+            return types.SimpleNamespace(input_ids=torch.tensor([r + [0] * (T - len(r)) for r in rows]))
+
+        def batch_decode(self, seqs, **k):
+            return ["x"] * len(seqs)
+
+    class T5Stub:
+        @staticmethod
+        def from_pretrained(*a, **k):
+            cfg = T5Config(vocab_size=VOC, d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2,
+                           num_heads=8, dropout_rate=0.1, feed_forward_proj="relu", tie_word_embeddings=True,
+                           decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
+            cfg._attn_implementation = "eager"
+            return T5ForConditionalGeneration(cfg)
+
+    tm.T5Tokenizer, tm.T5ForConditionalGeneration = Tok, T5Stub
+    tu.set_metrics = lambda m: None
+    cfg = rs.reference_config(**TINY)
+    cfg.update(load_path_t5="", t5_max_length=4, mm_encoder_inputs_include_cls_feats=True,
+               mm_encoder_inputs_include_imagetext_feats=False, mm_encoder_inputs_mm_feats_width=0)
+    torch.manual_seed(0)
+    # the wrapper constructs M3AETransformerSS itself: patch the loaders the same way build_reference_model does
+    rs.build_reference_model(cfg, **TINY_ARCH)
+    m = tm.T5VQA_MMEncoderInput(cfg)
+    m.unfreeze_top_layers(4, 4)
+    synth.fill_deterministic(m)  # names: m3ae.*, t5.*, feature_projection.*
+    # HF lists the tied embedding under several names (shared / embed_tokens / lm_head): make "t5.shared.weight" canonical
+    m.t5.shared.weight.data.copy_(synth.det_normal("t5.shared.weight", m.t5.shared.weight.shape, std=0.02))
+    proj = nn.Linear(256, 512)
+    proj.weight.data.copy_(synth.det_normal("cls_projection.weight", (512, 256), std=0.02))
+    proj.bias.data.copy_(synth.det_normal("cls_projection.bias", (512,), std=0.02))
+    m.projection_layer = lambda input_dim, output_dim=512: proj
+    m.eval()
+    for n in ("train", "val"):
+        for k in ("loss", "rouge1", "rouge2", "bleu_score", "exact_match"):
+            setattr(m, f"{n}_vqa_{k}", lambda *a, **kw: torch.tensor(0.0))
+    rs.chdir_ref()
+    batch = tiny_batch()
+    labels = synth.det_randint("t5_labels", 2, VOC, (2, 3), salt=5)
+    batch["vqa_answer"] = [[" ".join(str(int(t)) for t in labels[0])], [" ".join(str(int(t)) for t in labels[1, :2])]]
+    out = m.training_step(batch, 0)
+    loss = out["loss"]
+    loss.backward()
+    # logits through the same pieces
+    with torch.no_grad():
+        inp = m.prepare_inputs(batch, True, False, 0)
+        enc = m.t5.encoder(inputs_embeds=inp["inputs_embeds"], attention_mask=inp["attention_mask"])
+        lab = Tok()([a[0] for a in batch["vqa_answer"]]).input_ids
+        o = m.t5(encoder_outputs=enc, labels=lab, return_dict=True)
+    assert abs(o.loss.item() - loss.item()) < 1e-5
+    res = {"loss": np.float64(loss.item()), "logits": o.logits.numpy(), "labels": lab.numpy(),
+           "inputs_embeds_head": inp["inputs_embeds"][:, :4].numpy(), "enc_out": enc.last_hidden_state[:, :8].numpy()}
+    names, gn = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    res["grad_names"], res["grad_norm"] = np.array(names), np.array(gn)
+    res["trainable_names"] = np.array([n for n, p in m.named_parameters() if p.requires_grad])
+    np.savez_compressed(os.path.join(GOLD, "tiny_t5.npz"), **res)
+    print("[t5] loss", loss.item(), "trainable", len(res["trainable_names"]), "with grad", len(names))
+
+
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
     if "pretrain" in what:
         run_pretrain()
+    if "t5" in what:
+        run_t5()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
 

@@ -166,3 +166,48 @@ def test_full_size_bf16_step_and_optimizer():
     w = m.vqa_head[3].weight
     assert torch.equal(w.m3ae_c, w.data.to(torch.bfloat16))
     assert torch.equal(w.m3ae_t, w.data.to(torch.bfloat16).t().contiguous())
+
+
+T5_DIMS = dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2, num_heads=8)
+
+
+def _build_t5(mode, dtype):
+    from m3ae_amd.modules import T5VQA_MMEncoderInput
+    m = T5VQA_MMEncoderInput(tiny_config(compute_dtype=mode), t5_vocab=1100, t5_dims=T5_DIMS)
+    m.unfreeze_top_layers(4, 4)  # main_t5_m3ae.py:30
+    synth.fill_deterministic(m)
+    m.finalize("cuda", dtype)
+    m.eval()
+    return m
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_tiny_t5_generative_head_against_reference_fixture(mode):
+    """configs[2] path: frozen M3AE -> [prefix | projected CLS | zero pad to 512] -> T5 encoder -> teacher-forced decoder
+    -> tied LM head -> CE, forward + backward, vs the fixture captured from the reference's T5VQA_MMEncoderInput."""
+    dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    m = _build_t5(mode, dtype)
+    g = load_golden("tiny_t5.npz")
+    b = to_dev(tiny_batch())
+    b["t5_labels"] = torch.from_numpy(g["labels"]).cuda()
+    assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(
+        n for n in g["trainable_names"].tolist() if not n.startswith("feature_projection"))
+    m.store.zero_grad()
+    out = m(b)
+    loss = out["vqa_loss"]
+    logits = out["vqa_logits"].detach().float().cpu().numpy()
+    if mode == "fp32":
+        np.testing.assert_allclose(logits, g["logits"], rtol=1e-3, atol=1e-5)
+        assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    else:
+        assert np.abs(logits - g["logits"]).max() < 0.05 * max(1.0, np.abs(g["logits"]).max())
+        assert abs(loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
+    m.training_step(b)["loss"].backward()
+    params = dict(m.named_parameters())
+    tol = 2e-3 if mode == "fp32" else 8e-2
+    ref_total = float(np.sqrt((g["grad_norm"] ** 2).sum()))
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = params[n].grad.double().norm().item()
+        assert abs(mine - r) <= tol * r + 1e-3 * tol * ref_total, (n, mine, r)
+    m.store.adamw_step(max_steps=100, lr_factor=1.0)
+    assert torch.isfinite(m.store.flat).all()

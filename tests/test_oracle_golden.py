@@ -94,3 +94,37 @@ def test_full_size_forward_backward_matches_reference():
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
     loss.backward()
     _grad_check(sd, g, rtol=1e-3)
+
+
+def _t5_sd():
+    from m3ae_amd.modules import T5VQA_MMEncoderInput
+    with torch.device("meta"):
+        m = T5VQA_MMEncoderInput(tiny_config(), t5_vocab=1100, t5_dims=dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2,
+                                                                         num_decoder_layers=2, num_heads=8))
+    sd = {k: torch.empty(v.shape, dtype=torch.float32) for k, v in m.state_dict().items()}
+    from m3ae_amd import synth
+    synth.fill_deterministic(sd)
+    return sd
+
+
+def test_tiny_t5_head_matches_reference():
+    """configs[2] path (frozen M3AE -> T5 encoder/decoder -> CE) against the reference's T5VQA_MMEncoderInput."""
+    cfg = tiny_config()
+    sd = _t5_sd()
+    g = load_golden("tiny_t5.npz")
+    for t in sd.values():
+        t.requires_grad_(True)
+    m3 = {k[5:]: v for k, v in sd.items() if k.startswith("m3ae.")}
+    b = tiny_batch()
+    with torch.no_grad():
+        cls = O.infer(m3, oracle_cfg(cfg), b["image"][0], b["text_ids"], b["text_masks"])["multi_modal_cls_feats"]
+    x = O.t5_head_inputs(sd, cls, torch.tensor([822, 10]), sd["cls_projection.weight"], sd["cls_projection.bias"])
+    np.testing.assert_allclose(x[:, :4].detach().numpy(), g["inputs_embeds_head"], rtol=1e-4, atol=1e-6)
+    labels = torch.from_numpy(g["labels"])
+    loss, logits = O.t5_loss(sd, x, labels, 8)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = sd[n].grad.double().norm().item()
+        assert abs(mine - r) <= 1e-3 * r + 1e-9, (n, mine, r)
