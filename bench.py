@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("M3AE_BENCH_BATCH", 256)), help="per-GPU batch")
+    ap.add_argument("--head", choices=["cls", "t5"], default="cls",
+                    help="cls: configs[1] full fine-tune with the classification head (default, the timed metric); "
+                         "t5: configs[2] frozen M3AE + T5 generative head (main_t5_m3ae.py recipe)")
+    ap.add_argument("--t5", default="t5-small", help="t5-small (reference-faithful) | t5-base (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -94,8 +98,14 @@ def main():
 
     torch.set_num_threads(host_cores())
     log(f"rank {rank}/{world} on {dev}: building model")
-    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
-    model = M3AETransformerSS(cfg)
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16", t5_model_name=args.t5)
+    if args.head == "t5":
+        from m3ae_amd.modules import T5VQA_MMEncoderInput
+        model = T5VQA_MMEncoderInput(cfg)
+        model.unfreeze_top_layers(4, 4)  # run_scripts/finetune_m3ae.sh: unfreeze_num_{encoder,decoder}_layers=4
+        args.no_cpu_baseline = True      # the cpu_baseline leg times the configs[1] oracle
+    else:
+        model = M3AETransformerSS(cfg)
     synth.fill_deterministic(model)  # random-init weights of the named architecture (no checkpoints offline)
     model.finalize(dev, torch.bfloat16)
     model.eval()  # dropout is not applied on this path
@@ -106,11 +116,19 @@ def main():
     B = args.batch
     batch = to_dev(synth.synthetic_batch(B, text_len=32, image_size=384, rank=rank), dev)
     batch["vqa_targets"] = build_vqa_targets(batch, cfg["vqa_label_size"], dev)
+    if args.head == "t5":
+        lab = synth.det_randint("t5_labels", 2, 32128, (B, 6), salt=31 + rank)
+        lab[:, -1] = 1  # eos
+        batch["t5_labels"] = lab.to(dev)
     max_steps = args.steps + args.warmup + 16
+
+    def train_loss():
+        out = model.training_step(batch)
+        return out["loss"] if isinstance(out, dict) else out
 
     def step():
         store.zero_grad()
-        loss = model.training_step(batch)
+        loss = train_loss()
         loss.backward()
         reducer.finish()
         store.adamw_step(max_steps=max_steps, grad_scale=reducer.grad_scale)
@@ -148,7 +166,7 @@ def main():
         reducer.detach()
         for _ in range(2):
             store.zero_grad()
-            model.training_step(batch).backward()
+            train_loss().backward()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         agg = {}
@@ -184,14 +202,15 @@ def main():
                         "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
                         "flops_per_launch": fl / n}
         # fused cross-attention forward (all 6 layers, both directions), HIP events around the sub-blocks
+        m3 = model.m3ae if args.head == "t5" else model
         with torch.no_grad():
             dt_ = torch.bfloat16
             x = torch.randn(B, 32, 768, device=dev).to(dt_)
             y = torch.randn(B, 577, 768, device=dev).to(dt_)
-            mt = model.language_encoder.get_extended_attention_mask(batch["text_masks"]).contiguous()
+            mt = m3.language_encoder.get_extended_attention_mask(batch["text_masks"]).contiguous()
 
             def xattn_all():
-                for tl, il in zip(model.multi_modal_language_layers, model.multi_modal_vision_layers):
+                for tl, il in zip(m3.multi_modal_language_layers, m3.multi_modal_vision_layers):
                     tl.crossattention(x, None, y, None)
                     il.crossattention(y, None, x, mt)
             xattn_all()
@@ -233,16 +252,21 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "image-question pairs/sec, M3AE-base fine-tune step (fwd+bwd+AdamW) @384px",
+            "metric": "image-question pairs/sec, M3AE-base fine-tune step (fwd+bwd+AdamW) @384px" if args.head == "cls"
+            else f"image-question pairs/sec, M3AE-base(frozen)+{args.t5} generative-head fine-tune step @384px",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: M3AE-base (ViT-B/16 + RoBERTa-base + 6 co-attention layers) VQA-RAD "
-                                   "classification fine-tune, 384x384, 32 text tokens, 498 answers",
+            "config": {"workload": ("configs[1]: M3AE-base (ViT-B/16 + RoBERTa-base + 6 co-attention layers) VQA-RAD "
+                                    "classification fine-tune, 384x384, 32 text tokens, 498 answers") if args.head == "cls"
+                       else (f"configs[2] recipe: frozen M3AE-base forward + {args.t5} encoder (512 padded tokens) / "
+                             "teacher-forced decoder / tied LM head, top-4 encoder + top-4 decoder attention blocks "
+                             "trainable (main_t5_m3ae.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "dropout": "off (eval-mode semantics)", "weights": "random-init (synthetic, deterministic)"},
-            "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1),
-            "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4),
+            "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1) if args.head == "cls" else None,
+            "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
+            if args.head == "cls" else None,
             "final_loss": round(final_loss, 4),
             "roofline": roofline, "cross_attention_fwd": xattn, "kernels": kern_table, "cpu_baseline": cpu,
         }
