@@ -69,6 +69,8 @@ typedef struct {
     int32_t dact;
     int32_t force_generic; /* tests: bypass the MFMA kernels */
     float* a_rowsum;       /* optional fp32 [M]: a_rowsum[m] += sum_k A[m][k] (bias gradient fused into wgrad) */
+    float dropout_p;       /* > 0: x = dropout(x) after bias/activation, BEFORE the residual add (nn.Dropout of */
+    uint64_t dropout_seed; /*      bert_model.py:362,440); keep-mask = m3ae counter hash of (seed, m * N + n)     */
 } m3ae_gemm_desc;
 int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
 
@@ -101,6 +103,10 @@ typedef struct {
     void* dq; void* dk; void* dv;  /* layouts of q, k, v */
     float* delta;                  /* fp32 [B, H, lse_stride] scratch: rowsum(dO * O) */
     float* d_pos_bias;             /* fp32 [H, Lq, Lk], accumulated; or NULL */
+    /* attention-probability dropout (bert_model.py:334), bf16 kernels only: P is dropped (and rescaled by 1/(1-p))
+     * after the softmax normaliser is taken; mask = counter hash of (seed, ((b*H+h)*Lq+q)*Lk+k), regenerated in bwd */
+    float dropout_p;
+    uint64_t dropout_seed;
 } m3ae_attn_desc;
 int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward);
 int m3ae_attn_fwd(const m3ae_attn_desc* d, void* stream);
@@ -120,6 +126,16 @@ int64_t m3ae_layernorm_bwd_blocks(int64_t M);
 int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, void* dx, const void* dx_add, float* dgamma, float* dbeta, float* workspace,
                        int64_t M, int64_t D, int dtype, int act, int rms, void* stream);
+/* same, plus a second output dx_drop = dropout_mask(seed, p) * LN'(dy) / (1 - p): the gradient entering the dense layer
+ * whose output was dropped before the residual add (post-LN BERT blocks), produced without an extra pass over dx. */
+int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, void* dx, void* dx_drop, float dropout_p, uint64_t dropout_seed,
+                            float* dgamma, float* dbeta, float* workspace, int64_t M, int64_t D, int dtype,
+                            void* stream);
+/* out = dropout(x) with the library's counter-hash mask over the linear element index (forward and backward are the
+ * same map); keep_mask (uint8, optional) exports the mask for tests. */
+int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t n, float p, uint64_t seed, int dtype,
+                 void* stream);
 
 /* out[n] (+)= sum_m x[m][n]  (bias gradients; x has row stride ldx elements). */
 int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,

@@ -40,6 +40,8 @@ struct AttnArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     float* delta;
     float* d_pos_bias;
+    DropState drop;  // attention-probability dropout (bert_model.py:334)
+    int has_drop;
 };
 
 DEVINL f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
@@ -156,7 +158,7 @@ struct Flags { bool mask, bias, causal; };
 
 template <bool MASK, bool BIAS, bool CAUSAL, bool LAST>
 DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1, const AttnArgs& a, const float* mrow,
-                          const float* brow, int64_t key0, int64_t qi, int h) {
+                          const float* brow, int64_t key0, int64_t qi, int h, uint64_t drop_row = 0) {
     // log2-domain scores, additive mask / bias, bounds; online softmax update of (m, l, o)
     constexpr bool PLAIN = !MASK && !BIAS && !CAUSAL && !LAST;  // hot path: scale folded into the exp argument
     float tmax = -1e30f;
@@ -197,6 +199,11 @@ DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1,
         lsum += p;
     }
     l += lsum;
+    if (a.has_drop) {  // the normaliser keeps every key; only the P that multiplies V is dropped (and rescaled)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            s[reg] = drop_apply(a.drop, drop_row + (uint64_t)(key0 + crow(reg, h)), s[reg]);
+    }
 }
 
 template <int NQ, bool MASK, bool BIAS, bool CAUSAL>
@@ -617,8 +624,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
             const int64_t key0 = (int64_t)kt * 32;
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
-                if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
-                else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
+                const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi[n]) * a.Lk);
+                if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
+                else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -680,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 
     f32x16 g0 = zero16(), g1 = zero16();
     const int nkt = (int)((a.Lk + 31) / 32);
+    const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi) * a.Lk);
     s16x8 kreg = coop_load(kbase, a.k_sl, 0, a.Lk, t);
     s16x8 vreg = coop_load(vbase, a.v_sl, 0, a.Lk, t);
     put_row_img(lds, kreg, t);
@@ -717,7 +726,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
                 }
                 if (CAUSAL) valid = valid && key <= qi;
                 const float p = valid ? fast_exp2(x - lse) : 0.f;
-                const float ds = p * (dp[reg] - dlt);
+                float dpe = dp[reg];
+                if (a.has_drop) dpe = drop_apply(a.drop, drow + (uint64_t)key, dpe);  // dP wrt the un-dropped P
+                const float ds = p * (dpe - dlt);
                 if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
                 s[reg] = ds;
             }
@@ -812,8 +823,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
                 float x = fmaf(s[reg], a.scale_log2, mk);
                 if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
                 const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
-                p[reg] = pv;
-                s[reg] = pv * (dp[reg] - dl4[reg >> 2][reg & 3]);
+                float pd = pv, dpe = dp[reg];
+                if (a.has_drop) {
+                    const uint64_t di = (uint64_t)(((b * a.H + head) * a.Lq + (qq < a.Lq ? qq : a.Lq - 1)) * a.Lk + krow);
+                    const bool keep = drop_keep(a.drop, di);
+                    pd = keep ? pv * a.drop.inv_keep : 0.f;    // the P that multiplied V in the forward pass
+                    dpe = keep ? dpe * a.drop.inv_keep : 0.f;  // dP wrt the un-dropped P
+                }
+                p[reg] = pd;
+                s[reg] = pv * (dpe - dl4[reg >> 2][reg & 3]);
             }
             const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
             const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
@@ -949,6 +967,8 @@ AttnArgs to_args(const m3ae_attn_desc& d) {
     a.B = d.B; a.H = d.H; a.Lq = d.Lq; a.Lk = d.Lk;
     a.d_o = (const bf16_t*)d.d_o; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
     a.delta = d.delta; a.d_pos_bias = d.d_pos_bias;
+    a.has_drop = d.dropout_p > 0.f;
+    a.drop = make_drop(d.dropout_p, d.dropout_seed);
     return a;
 }
 
@@ -983,7 +1003,7 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
         if (!bf16_layout_ok(d, false)) return M3AE_ERR_UNSUPPORTED;
         if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
-        if (g_attn_coop) {
+        if (g_attn_coop || a.has_drop) {
             if (d.Lq > 32 && d.Lk > 64) {
                 dim3 grid((unsigned)cdiv(d.Lq, 256), (unsigned)d.H, (unsigned)d.B);
                 ATTN_DISPATCH3(attn_fwd_coop_kernel, grid, s, a, 2, );
@@ -1007,6 +1027,9 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
     float* S = (float*)d.workspace;
     int rc = attn_f32_scores(d, S, s);
     if (rc) return rc;
+    if (d.dropout_p > 0.f &&  // P is [B][H][Lq][Lk]: the linear index is the bf16 kernels' mask index
+        (rc = m3ae_dropout(S, S, nullptr, d.B * d.H * d.Lq * d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+        return rc;
     const int64_t QK = d.Lq * d.Lk;
     m3ae_gemm_desc g = bgemm(d);
     g.M = d.Lq; g.N = d.Dh; g.K = d.Lk;
@@ -1028,7 +1051,7 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        if (g_attn_coop) {
+        if (g_attn_coop || a.has_drop) {
             ATTN_DISPATCH3(attn_bwd_dq_coop_kernel, gq, s, a, );
             ATTN_DISPATCH3(attn_bwd_dkdv_coop_kernel, gk, s, a, );
         } else {
@@ -1040,10 +1063,13 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;
     if (!d.workspace || d.workspace_bytes < m3ae_attn_workspace_bytes(dp, 1)) return M3AE_ERR_WORKSPACE;
     const int64_t QK = d.Lq * d.Lk;
+    const bool drop = d.dropout_p > 0.f;
     float* P = (float*)d.workspace;
     float* dS = P + d.B * d.H * QK;
     int rc = attn_f32_scores(d, P, s);
     if (rc) return rc;
+    if (drop && (rc = m3ae_dropout(P, P, nullptr, d.B * d.H * QK, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+        return rc;  // dV below needs the dropped P that multiplied V in the forward pass
     // dP = dO . V^T
     m3ae_gemm_desc g = bgemm(d);
     g.M = d.Lq; g.N = d.Lk; g.K = d.Dh;
@@ -1059,6 +1085,11 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     g.C = d.dv; g.c_sm = d.v_sl; g.c_sn = 1; g.c_sb1 = d.v_sb; g.c_sb2 = d.Dh;
     if ((rc = m3ae_gemm_generic(g, s))) return rc;
     const int64_t rows = d.B * d.H * d.Lq;
+    if (drop) {  // the softmax backward needs the un-dropped P and dP wrt it
+        if ((rc = attn_f32_scores(d, P, s))) return rc;
+        if ((rc = m3ae_dropout(dS, dS, nullptr, d.B * d.H * QK, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+            return rc;
+    }
     hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, P, dS, rows, d.Lk);
     if (d.d_pos_bias) {
         const int64_t HQK = d.H * QK;

@@ -108,6 +108,36 @@ DEVINL float act_bwd_fast(float x, int act) {
     return act_bwd(x, act);
 }
 
+// ---- dropout: counter-based keep mask ---------------------------------------------------------------------
+// keep(seed, idx) = lowbias32(lo32(idx) ^ lowbias32(lo32(seed) + hi32(idx) * 0x9E3779B9 + hi32(seed))) >= p * 2^32.
+// Stateless, so forward and backward regenerate the same mask from (seed, element index) with ~10 integer ops.
+DEVINL uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct DropState { uint32_t key_lo, key_hi, thr; float inv_keep; };
+static inline DropState make_drop(float p, uint64_t seed) {
+    DropState d;
+    d.key_lo = (uint32_t)seed; d.key_hi = (uint32_t)(seed >> 32);
+    double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 4294967295U : (uint32_t)t;
+    d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+DEVINL DropState make_drop_dev(float p, uint64_t seed) {  // same as make_drop, callable on the device
+    DropState d;
+    d.key_lo = (uint32_t)seed; d.key_hi = (uint32_t)(seed >> 32);
+    const float t = p * 4294967296.0f;
+    d.thr = t >= 4294967040.0f ? 4294967295U : (uint32_t)t;
+    d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+DEVINL bool drop_keep(const DropState& d, uint64_t idx) {
+    const uint32_t k = lowbias32(d.key_lo + (uint32_t)(idx >> 32) * 0x9E3779B9U + d.key_hi);
+    return lowbias32((uint32_t)idx ^ k) >= d.thr;
+}
+DEVINL float drop_apply(const DropState& d, uint64_t idx, float x) { return drop_keep(d, idx) ? x * d.inv_keep : 0.f; }
+
 DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

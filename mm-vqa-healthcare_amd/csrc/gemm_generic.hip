@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
         }
     }
 
+    const DropState drop = make_drop_dev(d.dropout_p, d.dropout_seed);
     TC* C = (TC*)d.C + coff;
     TC* P = d.preact ? (TC*)d.preact + coff : nullptr;
     const TC* R = d.residual ? (const TC*)d.residual + coff : nullptr;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
             if (d.bias) x += d.bias[gn];
             if (P) Elem<TC>::st(P + off, x);
             x = act_fwd(x, d.act);
+            if (d.dropout_p > 0.f) x = drop_apply(drop, (uint64_t)(gm * d.N + gn), x);
             if (R) x += Elem<TC>::ld(R + off);
             if (X) x *= act_bwd(Elem<TC>::ld(X + off), d.dact);
             if (d.accumulate) x += Elem<TC>::ld(C + off);

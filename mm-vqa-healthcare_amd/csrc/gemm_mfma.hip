@@ -44,6 +44,8 @@ struct MfmaArgs {
     const void* dact_aux;
     int dact;
     float* a_rowsum;  // TN only: fp32 [N1] += column sums of A (bias gradient)
+    DropState drop;   // NT only: dropout on (acc + bias), before the residual add
+    int has_drop;
     int rows_epi;     // NT only: LDS-transposed row-contiguous epilogue (N % 8 == 0)
     int splits;       // TN only
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
@@ -127,6 +129,10 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = act_fwd_fast(x[t], act);
     }
+    if (a.has_drop) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = drop_apply(a.drop, (uint64_t)(m * a.N + n + t), x[t]);
+    }
     if (a.residual) {
         Vec4<TC>::ld((const TC*)a.residual + off, y);
 #pragma unroll
@@ -181,6 +187,10 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x) {
         const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = act_fwd_fast(x[t], act);
+    }
+    if (a.has_drop) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = drop_apply(a.drop, (uint64_t)(m * a.N + n + t), x[t]);
     }
     if (a.residual) {
         Vec8<TC>::ld((const TC*)a.residual + off, y);
@@ -550,6 +560,8 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.alpha = d.alpha; a.accumulate = d.accumulate; a.bias = d.bias; a.act = d.act; a.preact = d.preact;
     a.residual = d.residual; a.dact_aux = d.dact_aux; a.dact = d.dact;
     a.rows_epi = (d.N % 8 == 0 && d.c_sm % 8 == 0) ? 1 : 0;
+    a.has_drop = d.dropout_p > 0.f;
+    a.drop = make_drop(d.dropout_p, d.dropout_seed);
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
     if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);

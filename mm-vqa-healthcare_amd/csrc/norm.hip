@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 template <typename T, int CPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* beta,
                                                      const float* mean_i, const float* rstd_i, T* dx, const T* dx_add,
-                                                     float* part, int64_t M, int D, int act, int rms) {
+                                                     float* part, int64_t M, int D, int act, int rms, T* dx_drop,
+                                                     DropState drop) {
     extern __shared__ float red[];  // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -137,6 +138,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
                 float o[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = rstd * (dxh[c][t] - c1 - xh[c][t] * c2);
+                if (dx_drop) {
+                    float od[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) od[t] = drop_apply(drop, (uint64_t)(row * D + ch * 4 + t), o[t]);
+                    st4<T>(dx_drop + row * D + ch * 4, od);
+                }
                 if (dx_add) {
                     float e[4];
                     ld4<T>(dx_add + row * D + ch * 4, e);
@@ -204,9 +211,11 @@ int launch_fwd(const void* x, const float* g, const float* b, void* y, float* me
 }
 template <typename T, int CPL>
 int launch_bwd(const void* dy, const void* x, const float* g, const float* b, const float* mean, const float* rstd,
-               void* dx, const void* dx_add, float* part, int nblk, int64_t M, int D, int act, int rms, hipStream_t s) {
+               void* dx, const void* dx_add, float* part, int nblk, int64_t M, int D, int act, int rms, hipStream_t s,
+               void* dx_drop = nullptr, DropState drop = DropState{}) {
     hipLaunchKernelGGL((ln_bwd_kernel<T, CPL>), dim3((unsigned)nblk), dim3(256), (size_t)8 * D * sizeof(float), s,
-                       (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, (const T*)dx_add, part, M, D, act, rms);
+                       (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, (const T*)dx_add, part, M, D, act, rms,
+                       (T*)dx_drop, drop);
     return hip_launch_status();
 }
 
@@ -262,5 +271,29 @@ extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* ga
     if (!dgamma) return 0;
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 32), (unsigned)cdiv(nblk, 64)), dim3(256), 0, s, workspace, dgamma,
                        dbeta, nblk, (int)D);
+    return hip_launch_status();
+}
+
+extern "C" int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* beta,
+                                       const float* mean, const float* rstd, void* dx, void* dx_drop, float dropout_p,
+                                       uint64_t dropout_seed, float* dgamma, float* dbeta, float* workspace, int64_t M,
+                                       int64_t D, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !rstd || !dx || !dx_drop || !workspace || M <= 0) return M3AE_ERR_ARG;
+    if (D % 4 != 0 || D > 2048) return M3AE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)m3ae_layernorm_bwd_blocks(M);
+    const DropState drop = make_drop(dropout_p, dropout_seed);
+    auto run = [&]() -> int {
+        if (dtype == M3AE_F32)
+            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, nblk, M, (int)D, 0, 0, s, dx_drop, drop);
+        if (dtype == M3AE_BF16)
+            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, nblk, M, (int)D, 0, 0, s, dx_drop, drop);
+        return M3AE_ERR_UNSUPPORTED;
+    };
+    int rc = run();
+    if (rc) return rc;
+    if (!dgamma) return 0;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 32), (unsigned)cdiv(nblk, 64)), dim3(256), 0, s,
+                       workspace, dgamma, dbeta, nblk, (int)D);
     return hip_launch_status();
 }

@@ -20,6 +20,7 @@ class GemmDesc(C.Structure):
         ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
         ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
         ("dact_aux", vp), ("dact", i32), ("force_generic", i32), ("a_rowsum", vp),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -33,6 +34,7 @@ class AttnDesc(C.Structure):
         ("key_mask", vp), ("pos_bias", vp), ("scale", f32), ("causal", i32),
         ("lse", vp), ("lse_stride", i64), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
         ("d_o", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp), ("d_pos_bias", vp),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -46,6 +48,8 @@ _SIGS = {
     "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
     "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "m3ae_layernorm_bwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp, vp, vp, i64, i64, C.c_int, vp]),
+    "m3ae_dropout": (C.c_int, [vp, vp, vp, i64, f32, C.c_uint64, C.c_int, vp]),
     "m3ae_colsum": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),

@@ -58,18 +58,25 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(hidden, eps)
         self.cross = cross
 
-    def forward(self, h, key_mask=None, other=None, other_mask=None):
+    def forward(self, h, key_mask=None, other=None, other_mask=None, pdrop=0.0):
+        """Op-level composition (A/B reference of the fused blocks).  Draws its dropout seeds in the same order as
+        ops._attn_sub_fwd, so fused and unfused runs started from one `ops.set_dropout_seed` use identical masks."""
         heads = self.self.num_attention_heads
+        da = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
+        dh = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
         if other is None:
             w, b = self.self.pack("qkv")
             qkv = ops.linear(h, w, b)
-            ctx = ops.self_attention(qkv, key_mask, heads)
+            ctx = ops.self_attention(qkv, key_mask, heads, da)
         else:
             q = ops.linear(h, self.self.query.weight, self.self.query.bias)
             w, b = self.self.pack("kv")
             kv = ops.linear(other, w, b)
-            ctx = ops.cross_attention(q, kv, other_mask, heads)
-        s = ops.linear(ctx, self.output.dense.weight, self.output.dense.bias, residual=h)
+            ctx = ops.cross_attention(q, kv, other_mask, heads, da)
+        if dh is None:
+            s = ops.linear(ctx, self.output.dense.weight, self.output.dense.bias, residual=h)
+        else:
+            s = ops.DropoutFn.apply(ops.linear(ctx, self.output.dense.weight, self.output.dense.bias), *dh) + h
         ln = self.output.LayerNorm
         return ops.layer_norm(s, ln.weight, ln.bias, ln.eps)
 
@@ -106,10 +113,16 @@ class BertOutput(nn.Module):
         self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
 
 
-def _ffn(layer, h):
+def _ffn(layer, h, pdrop=0.0):
     """feed_forward_chunk (bert_model.py:500-503)."""
-    s = ops.mlp(h, layer.intermediate.dense.weight, layer.intermediate.dense.bias, layer.output.dense.weight,
-                layer.output.dense.bias, ops.ACT_GELU, residual=h)
+    if pdrop > 0:
+        seed = ops.next_dropout_seed()
+        s = ops.mlp(h, layer.intermediate.dense.weight, layer.intermediate.dense.bias, layer.output.dense.weight,
+                    layer.output.dense.bias, ops.ACT_GELU)
+        s = ops.DropoutFn.apply(s, pdrop, seed) + h
+    else:
+        s = ops.mlp(h, layer.intermediate.dense.weight, layer.intermediate.dense.bias, layer.output.dense.weight,
+                    layer.output.dense.bias, ops.ACT_GELU, residual=h)
     ln = layer.output.LayerNorm
     return ops.layer_norm(s, ln.weight, ln.bias, ln.eps)
 
@@ -117,8 +130,9 @@ def _ffn(layer, h):
 class BertCrossLayer(nn.Module):
     """bert_model.py:445-503: self-attention -> cross-attention (residual = self-attention output) -> FFN."""
 
-    def __init__(self, hidden, heads, inter, eps=1e-12):
+    def __init__(self, hidden, heads, inter, eps=1e-12, drop_rate=0.0):
         super().__init__()
+        self.drop_rate = drop_rate  # hidden_dropout_prob = attention_probs_dropout_prob (m3ae_module.py:31-32)
         self.attention = BertAttention(hidden, heads, eps)
         self.crossattention = BertAttention(hidden, heads, eps, cross=True)
         self.intermediate = BertIntermediate(hidden, inter)
@@ -130,14 +144,16 @@ class BertCrossLayer(nn.Module):
             self._bp = NS(attn=self.attention.block_params(), cross=self.crossattention.block_params(),
                           ffn=_ffn_params(self))
             self._anchors = tuple(self.parameters())
+        self._bp.pdrop = self.drop_rate if self.training else 0.0
         return ops.BertCrossLayerFn.apply(hidden_states, encoder_hidden_states, attention_mask, encoder_attention_mask,
                                           self._bp, *self._anchors)
 
     def forward_unfused(self, hidden_states, encoder_hidden_states, attention_mask=None, encoder_attention_mask=None):
         """Op-level composition (one autograd node per kernel group); kept for A/B checks against the fused node."""
-        a = self.attention(hidden_states, attention_mask)
-        c = self.crossattention(a, None, encoder_hidden_states, encoder_attention_mask)
-        return _ffn(self, c)
+        pd = self.drop_rate if self.training else 0.0
+        a = self.attention(hidden_states, attention_mask, pdrop=pd)
+        c = self.crossattention(a, None, encoder_hidden_states, encoder_attention_mask, pdrop=pd)
+        return _ffn(self, c, pd)
 
     def weight_units(self):
         return (self.attention.weight_units() + self.crossattention.weight_units()
@@ -147,8 +163,9 @@ class BertCrossLayer(nn.Module):
 class BertSelfLayer(nn.Module):
     """bert_model.py:506-546 == HF RobertaLayer (called at m3ae_module.py:233-234)."""
 
-    def __init__(self, hidden, heads, inter, eps=1e-5):
+    def __init__(self, hidden, heads, inter, eps=1e-5, drop_rate=0.0):
         super().__init__()
+        self.drop_rate = drop_rate
         self.attention = BertAttention(hidden, heads, eps)
         self.intermediate = BertIntermediate(hidden, inter)
         self.output = BertOutput(hidden, inter, eps)
@@ -158,10 +175,12 @@ class BertSelfLayer(nn.Module):
         if self._bp is None:
             self._bp = NS(attn=self.attention.block_params(), ffn=_ffn_params(self))
             self._anchors = tuple(self.parameters())
+        self._bp.pdrop = self.drop_rate if self.training else 0.0
         return ops.BertSelfLayerFn.apply(hidden_states, attention_mask, self._bp, *self._anchors)
 
     def forward_unfused(self, hidden_states, attention_mask=None):
-        return _ffn(self, self.attention(hidden_states, attention_mask))
+        pd = self.drop_rate if self.training else 0.0
+        return _ffn(self, self.attention(hidden_states, attention_mask, pdrop=pd), pd)
 
     def weight_units(self):
         return self.attention.weight_units() + [self.intermediate.dense.weight, self.output.dense.weight]
@@ -170,8 +189,9 @@ class BertSelfLayer(nn.Module):
 class RobertaEmbeddings(nn.Module):
     """HF RobertaEmbeddings (third party; m3ae_module.py:230)."""
 
-    def __init__(self, vocab, hidden, max_pos, type_vocab=1, pad_id=1, eps=1e-5):
+    def __init__(self, vocab, hidden, max_pos, type_vocab=1, pad_id=1, eps=1e-5, drop_rate=0.0):
         super().__init__()
+        self.drop_rate = drop_rate
         self.word_embeddings = nn.Embedding(vocab, hidden, padding_idx=pad_id)
         self.position_embeddings = nn.Embedding(max_pos, hidden, padding_idx=pad_id)
         self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
@@ -181,13 +201,15 @@ class RobertaEmbeddings(nn.Module):
     def forward(self, input_ids, dtype):
         e = ops.roberta_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                               self.token_type_embeddings.weight, self.padding_idx, dtype)
-        return ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        y = ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        return ops.dropout(y, self.drop_rate, self.training)
 
 
 class RobertaEncoder(nn.Module):
-    def __init__(self, layers, hidden, heads, inter):
+    def __init__(self, layers, hidden, heads, inter, drop_rate=0.0):
         super().__init__()
-        self.layer = nn.ModuleList([BertSelfLayer(hidden, heads, inter, eps=1e-5) for _ in range(layers)])
+        self.layer = nn.ModuleList([BertSelfLayer(hidden, heads, inter, eps=1e-5, drop_rate=drop_rate)
+                                    for _ in range(layers)])
 
 
 class RobertaPooler(nn.Module):
@@ -202,10 +224,11 @@ class RobertaModel(nn.Module):
     """Parameter-name-compatible stand-in for transformers' RobertaModel as the reference uses it
     (m3ae_module.py:66,230-234): embeddings + encoder.layer[*]; `pooler` kept for key compatibility."""
 
-    def __init__(self, vocab, hidden, layers, heads, inter, max_pos=514):
+    def __init__(self, vocab, hidden, layers, heads, inter, max_pos=514, drop_rate=0.1):
         super().__init__()
-        self.embeddings = RobertaEmbeddings(vocab, hidden, max_pos)
-        self.encoder = RobertaEncoder(layers, hidden, heads, inter)
+        # roberta-base ships hidden_dropout_prob = attention_probs_dropout_prob = 0.1 (RobertaModel.from_pretrained)
+        self.embeddings = RobertaEmbeddings(vocab, hidden, max_pos, drop_rate=drop_rate)
+        self.encoder = RobertaEncoder(layers, hidden, heads, inter, drop_rate=drop_rate)
         self.pooler = RobertaPooler(hidden)
 
     @staticmethod

@@ -67,9 +67,9 @@ class M3AETransformerSS(_Base):
         self.modality_type_embeddings = nn.Embedding(2, hs)
         inter = hs * cfg["mlp_ratio"]
         self.multi_modal_vision_layers = nn.ModuleList(
-            [BertCrossLayer(hs, cfg["num_heads"], inter) for _ in range(cfg["num_top_layer"])])
+            [BertCrossLayer(hs, cfg["num_heads"], inter, drop_rate=cfg["drop_rate"]) for _ in range(cfg["num_top_layer"])])
         self.multi_modal_language_layers = nn.ModuleList(
-            [BertCrossLayer(hs, cfg["num_heads"], inter) for _ in range(cfg["num_top_layer"])])
+            [BertCrossLayer(hs, cfg["num_heads"], inter, drop_rate=cfg["drop_rate"]) for _ in range(cfg["num_top_layer"])])
         self.multi_modal_vision_pooler = prediction_heads.Pooler(hs)
         self.multi_modal_language_pooler = prediction_heads.Pooler(hs)
         for m in (self.multi_modal_language_proj, self.multi_modal_vision_proj, self.modality_type_embeddings,

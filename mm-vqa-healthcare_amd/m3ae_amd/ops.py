@@ -34,6 +34,22 @@ def _prof_end(e0, kind, dims):
     PROFILE.append((kind, dims, e0, e1))
 
 
+# dropout seeds: every dropout site of every forward call draws a fresh 64-bit seed from this counter stream; the
+# site stores it for its backward.  `set_dropout_seed` makes a run reproducible.
+_drop_base, _drop_ctr = 0x5EED, 0
+
+
+def set_dropout_seed(seed):
+    global _drop_base, _drop_ctr
+    _drop_base, _drop_ctr = int(seed) & 0xFFFFFFFF, 0
+
+
+def next_dropout_seed():
+    global _drop_ctr
+    _drop_ctr += 1
+    return ((_drop_base << 32) | (_drop_ctr & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -65,7 +81,7 @@ def compute_weight(w):
 # ----------------------------------------------------------------------------------------------------------
 def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulate=False, bias=None, act=ACT_NONE,
          preact=None, residual=None, dact_aux=None, dact=ACT_NONE, force_generic=False, batch=(1, 1),
-         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0), a_rowsum=None):
+         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0), a_rowsum=None, dropout=None):
     _need_cuda(c)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -89,6 +105,8 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
     if a_rowsum is not None:
         assert a_rowsum.dtype == torch.float32 and a_rowsum.numel() >= M and batch == (1, 1)
         d.a_rowsum = a_rowsum.data_ptr()
+    if dropout is not None and dropout[0] > 0:
+        d.dropout_p, d.dropout_seed = dropout
     e0 = _prof_begin()
     check(_lib.lib().m3ae_gemm(C.byref(d), _stream()), "m3ae_gemm")
     if e0 is not None:
@@ -112,13 +130,13 @@ def _rows(x):
 
 
 def mm_nt(x2, ldx, M, w, bias=None, act=ACT_NONE, residual=None, want_preact=False, out_dtype=None, dact_aux=None,
-          dact=ACT_NONE, force_generic=False, alpha=1.0):
+          dact=ACT_NONE, force_generic=False, alpha=1.0, dropout=None):
     """y[M,N] = epi(alpha * x2[M,K] . w[N,K]^T)."""
     N, K = w.shape
     y = torch.empty((M, N), dtype=out_dtype or x2.dtype, device=x2.device)
     pre = torch.empty_like(y) if want_preact else None
     gemm(x2, ldx, 1, w, 1, w.stride(0), y, N, M, N, K, bias=bias, act=act, preact=pre, residual=residual,
-         dact_aux=dact_aux, dact=dact, force_generic=force_generic, alpha=alpha)
+         dact_aux=dact_aux, dact=dact, force_generic=force_generic, alpha=alpha, dropout=dropout)
     return y, pre
 
 
@@ -371,8 +389,9 @@ def ln_fwd_raw(x2, ln, act=ACT_NONE, rms=False):
     return y, mean, rstd
 
 
-def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE, rms=False):
-    """dx = LN'(dy) (+ dx_add); ln.weight.grad / ln.bias.grad accumulate in place."""
+def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE, rms=False, drop=None):
+    """dx = LN'(dy) (+ dx_add); ln.weight.grad / ln.bias.grad accumulate in place.  With drop = (p, seed) returns
+    (dx, dx_drop): dx_drop is dx under the dropout mask of the dense layer that fed this LayerNorm."""
     M, D = x2.shape
     L = _lib.lib()
     dx = torch.empty_like(x2)
@@ -381,6 +400,16 @@ def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE, rms=False):
     train = ln.weight.requires_grad
     gg = _grad_buf(ln.weight) if train else None
     gb = _grad_buf(ln.bias) if (train and ln.bias is not None) else None
+    if drop is not None and drop[0] > 0:
+        assert dx_add is None and act == ACT_NONE and not rms
+        dxd = torch.empty_like(x2)
+        check(L.m3ae_layernorm_bwd_drop(_p(dy), _p(x2), _p(ln.weight), _p(ln.bias), _p(mean), _p(rstd), _p(dx), _p(dxd),
+                                        drop[0], drop[1], _p(gg), _p(gb), _p(ws), M, D, _dt(x2), _stream()),
+              "m3ae_layernorm_bwd_drop")
+        if train:
+            _done(ln.weight)
+            _done(ln.bias)
+        return dx, dxd
     check(L.m3ae_layernorm_bwd(_p(dy), _p(x2), _p(ln.weight), _p(ln.bias), _p(mean), _p(rstd), _p(dx), _p(dx_add),
                                _p(gg), _p(gb), _p(ws), M, D, _dt(x2), act, int(rms), _stream()), "m3ae_layernorm_bwd")
     if train:
@@ -417,7 +446,7 @@ def _attn_ws(d, backward, device):
     return ws
 
 
-def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causal=False):
+def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causal=False, dropout=None):
     """q [B,Lq,D] / k,v [B,Lk,D] (last dim contiguous, any batch/token strides) -> o [B,Lq,D], lse."""
     _need_cuda(q)
     B, Lq, D = q.shape
@@ -428,6 +457,8 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     lse_stride = (Lq + 31) // 32 * 32
     lse = torch.empty((B, heads, lse_stride), dtype=torch.float32, device=q.device)
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
+    if dropout is not None and dropout[0] > 0:
+        d.dropout_p, d.dropout_seed = dropout
     ws = _attn_ws(d, False, q.device)
     e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_fwd(C.byref(d), _stream()), "m3ae_attn_fwd")
@@ -437,7 +468,7 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
 
 
 def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bias=None, scale=None, causal=False,
-                  d_pos_bias=None):
+                  d_pos_bias=None, dropout=None):
     B, Lq, D = q.shape
     Lk = k.shape[1]
     Dh = D // heads
@@ -447,6 +478,8 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     delta = torch.empty_like(lse)
     d.d_o, d.dq, d.dk, d.dv, d.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
+    if dropout is not None and dropout[0] > 0:
+        d.dropout_p, d.dropout_seed = dropout
     ws = _attn_ws(d, True, q.device)
     e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_bwd(C.byref(d), _stream()), "m3ae_attn_bwd")
@@ -458,12 +491,12 @@ class SelfAttnFn(torch.autograd.Function):
     """softmax(QK^T / sqrt(dh) + mask) V on a packed [B, L, 3D] projection (rows Q | K | V)."""
 
     @staticmethod
-    def forward(ctx, qkv, key_mask, heads):
+    def forward(ctx, qkv, key_mask, heads, dropout=None):
         D = qkv.shape[-1] // 3
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-        o, lse = attn_forward(q, k, v, heads, key_mask)
+        o, lse = attn_forward(q, k, v, heads, key_mask, dropout=dropout)
         ctx.save_for_backward(qkv, o, lse, key_mask)
-        ctx.heads = heads
+        ctx.heads, ctx.dropout = heads, dropout
         return o
 
     @staticmethod
@@ -472,19 +505,19 @@ class SelfAttnFn(torch.autograd.Function):
         D = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
         attn_backward(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), dqkv[..., :D],
-                      dqkv[..., D:2 * D], dqkv[..., 2 * D:], ctx.heads, key_mask)
-        return dqkv, None, None
+                      dqkv[..., D:2 * D], dqkv[..., 2 * D:], ctx.heads, key_mask, dropout=ctx.dropout)
+        return dqkv, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):
     """Q from this stream [B, Lq, D]; packed K | V [B, Lk, 2D] from the other stream (bert_model.py:275-278)."""
 
     @staticmethod
-    def forward(ctx, q, kv, key_mask, heads):
+    def forward(ctx, q, kv, key_mask, heads, dropout=None):
         D = q.shape[-1]
-        o, lse = attn_forward(q, kv[..., :D], kv[..., D:], heads, key_mask)
+        o, lse = attn_forward(q, kv[..., :D], kv[..., D:], heads, key_mask, dropout=dropout)
         ctx.save_for_backward(q, kv, o, lse, key_mask)
-        ctx.heads = heads
+        ctx.heads, ctx.dropout = heads, dropout
         return o
 
     @staticmethod
@@ -494,16 +527,17 @@ class CrossAttnFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         attn_backward(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), dq, dkv[..., :D], dkv[..., D:], ctx.heads,
-                      key_mask)
-        return dq, dkv, None, None
+                      key_mask, dropout=ctx.dropout)
+        return dq, dkv, None, None, None
 
 
-def self_attention(qkv, key_mask, heads):
-    return SelfAttnFn.apply(qkv, key_mask, heads)
+def self_attention(qkv, key_mask, heads, dropout=None):
+    """dropout = (p, seed): attention-probability dropout (mask index ((b*H + h)*Lq + q)*Lk + k)."""
+    return SelfAttnFn.apply(qkv, key_mask, heads, dropout)
 
 
-def cross_attention(q, kv, key_mask, heads):
-    return CrossAttnFn.apply(q, kv, key_mask, heads)
+def cross_attention(q, kv, key_mask, heads, dropout=None):
+    return CrossAttnFn.apply(q, kv, key_mask, heads, dropout)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -516,72 +550,82 @@ def _bdata(b):
     return None if b is None else (b.data if hasattr(b, "members") else b.detach())
 
 
-def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P):
-    """BertAttention (bert_model.py:367-413) on 2-D token-major activations. Returns (y, saved)."""
+def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
+    """BertAttention (bert_model.py:367-413) on 2-D token-major activations. Returns (y, saved).
+    pdrop > 0 (training): attention-probability dropout (:334) and hidden dropout on the output dense (:362)."""
     heads = P.heads
     D = h2.shape[1]
+    da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
+    dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     if other2 is None:
         qkv, _ = mm_nt(h2, D, B * L, compute_weight(P.w_qkv), bias=_bdata(P.b_qkv))
         v3 = qkv.view(B, L, 3 * D)
-        o, lse = attn_forward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], heads, mask)
+        o, lse = attn_forward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], heads, mask, dropout=da)
         proj = (qkv,)
     else:
         q, _ = mm_nt(h2, D, B * L, compute_weight(P.w_q), bias=_bdata(P.b_q))
         kv, _ = mm_nt(other2, other2.shape[1], B * Lo, compute_weight(P.w_kv), bias=_bdata(P.b_kv))
         kv3 = kv.view(B, Lo, 2 * D)
-        o, lse = attn_forward(q.view(B, L, D), kv3[..., :D], kv3[..., D:], heads, mask)
+        o, lse = attn_forward(q.view(B, L, D), kv3[..., :D], kv3[..., D:], heads, mask, dropout=da)
         proj = (q, kv)
     o2 = o.view(B * L, D)
-    s, _ = mm_nt(o2, D, B * L, compute_weight(P.w_o), bias=_bdata(P.b_o), residual=h2)
+    s, _ = mm_nt(o2, D, B * L, compute_weight(P.w_o), bias=_bdata(P.b_o), residual=h2, dropout=dh)
     y, mean, rstd = ln_fwd_raw(s, P.ln)
-    return y, (h2, other2, proj, o, lse, s, mean, rstd, mask)
+    return y, (h2, other2, proj, o, lse, s, mean, rstd, mask, da, dh)
 
 
 def _attn_sub_bwd(dy, saved, B, L, Lo, P, need_dother=True):
-    h2, other2, proj, o, lse, s, mean, rstd, mask = saved
+    h2, other2, proj, o, lse, s, mean, rstd, mask, da, dh = saved
     D = h2.shape[1]
-    ds = ln_bwd_raw(dy, s, P.ln, mean, rstd)
+    if dh is not None:
+        ds, dsd = ln_bwd_raw(dy, s, P.ln, mean, rstd, drop=dh)  # dsd: gradient of the (dropped) dense output
+    else:
+        ds = dsd = ln_bwd_raw(dy, s, P.ln, mean, rstd)
     o2 = o.view(B * L, D)
-    mm_wgrad(ds, o2, D, P.w_o, P.b_o)
-    dctx = mm_dgrad(ds, P.w_o)
+    mm_wgrad(dsd, o2, D, P.w_o, P.b_o)
+    dctx = mm_dgrad(dsd, P.w_o)
     if other2 is None:
         (qkv,) = proj
         v3 = qkv.view(B, L, 3 * D)
         dqkv = torch.empty_like(qkv)
         d3 = dqkv.view(B, L, 3 * D)
         attn_backward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], o, lse, dctx.view(B, L, D), d3[..., :D],
-                      d3[..., D:2 * D], d3[..., 2 * D:], P.heads, mask)
+                      d3[..., D:2 * D], d3[..., 2 * D:], P.heads, mask, dropout=da)
         mm_wgrad(dqkv, h2, D, P.w_qkv, P.b_qkv)
-        dh = mm_dgrad(dqkv, P.w_qkv, residual=ds)  # + residual-branch gradient, fused
-        return dh, None
+        dhid = mm_dgrad(dqkv, P.w_qkv, residual=ds)  # + residual-branch gradient, fused
+        return dhid, None
     q, kv = proj
     kv3 = kv.view(B, Lo, 2 * D)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     dkv3 = dkv.view(B, Lo, 2 * D)
     attn_backward(q.view(B, L, D), kv3[..., :D], kv3[..., D:], o, lse, dctx.view(B, L, D), dq.view(B, L, D),
-                  dkv3[..., :D], dkv3[..., D:], P.heads, mask)
+                  dkv3[..., :D], dkv3[..., D:], P.heads, mask, dropout=da)
     mm_wgrad(dq, h2, D, P.w_q, P.b_q)
     mm_wgrad(dkv, other2, other2.shape[1], P.w_kv, P.b_kv)
-    dh = mm_dgrad(dq, P.w_q, residual=ds)
+    dhid = mm_dgrad(dq, P.w_q, residual=ds)
     dother = mm_dgrad(dkv, P.w_kv) if need_dother else None
-    return dh, dother
+    return dhid, dother
 
 
-def _ffn_sub_fwd(h2, P):
-    """BertIntermediate + BertOutput (bert_model.py:416-442, 500-503)."""
+def _ffn_sub_fwd(h2, P, pdrop=0.0):
+    """BertIntermediate + BertOutput (bert_model.py:416-442, 500-503); pdrop: hidden dropout on the output dense (:440)."""
     M, D = h2.shape
+    dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     g, u = mm_nt(h2, D, M, compute_weight(P.w1), bias=_bdata(P.b1), act=ACT_GELU, want_preact=True)
-    s, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), bias=_bdata(P.b2), residual=h2)
+    s, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), bias=_bdata(P.b2), residual=h2, dropout=dh)
     y, mean, rstd = ln_fwd_raw(s, P.ln)
-    return y, (h2, u, g, s, mean, rstd)
+    return y, (h2, u, g, s, mean, rstd, dh)
 
 
 def _ffn_sub_bwd(dy, saved, P):
-    h2, u, g, s, mean, rstd = saved
-    ds = ln_bwd_raw(dy, s, P.ln, mean, rstd)
-    mm_wgrad(ds, g, g.shape[1], P.w2, P.b2)
-    du = mm_dgrad(ds, P.w2, dact_aux=u, dact=ACT_GELU)
+    h2, u, g, s, mean, rstd, dh = saved
+    if dh is not None:
+        ds, dsd = ln_bwd_raw(dy, s, P.ln, mean, rstd, drop=dh)
+    else:
+        ds = dsd = ln_bwd_raw(dy, s, P.ln, mean, rstd)
+    mm_wgrad(dsd, g, g.shape[1], P.w2, P.b2)
+    du = mm_dgrad(dsd, P.w2, dact_aux=u, dact=ACT_GELU)
     mm_wgrad(du, h2, h2.shape[1], P.w1, P.b1)
     return mm_dgrad(du, P.w1, residual=ds)
 
@@ -595,9 +639,10 @@ class BertCrossLayerFn(torch.autograd.Function):
         Lo = other.shape[1]
         h2 = h.contiguous().view(B * L, D)
         other2 = other.contiguous().view(B * Lo, other.shape[2])
-        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask_self, P.attn)
-        c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross)
-        y, s3 = _ffn_sub_fwd(c, P.ffn)
+        pd = getattr(P, "pdrop", 0.0)
+        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask_self, P.attn, pd)
+        c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross, pd)
+        y, s3 = _ffn_sub_fwd(c, P.ffn, pd)
         ctx.saved = (s1, s2, s3)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, Lo, D), len(anchors)
         ctx.need_other = other.requires_grad
@@ -623,8 +668,9 @@ class BertSelfLayerFn(torch.autograd.Function):
     def forward(ctx, h, mask, P, *anchors):
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
-        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask, P.attn)
-        y, s3 = _ffn_sub_fwd(a, P.ffn)
+        pd = getattr(P, "pdrop", 0.0)
+        a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask, P.attn, pd)
+        y, s3 = _ffn_sub_fwd(a, P.ffn, pd)
         ctx.saved = (s1, s3)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
         return y.view(B, L, D)
@@ -1005,6 +1051,38 @@ class GatherRowsFn(torch.autograd.Function):
 
 def gather_rows(src, flat_idx):
     return GatherRowsFn.apply(src, flat_idx)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout as a standalone op (RoBERTa embeddings, HF RobertaEmbeddings.dropout; m3ae_module.py:230)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        check(_lib.lib().m3ae_dropout(_p(xc), _p(y), None, xc.numel(), p, seed, _dt(xc), _stream()), "m3ae_dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = dy.contiguous()
+        dx = torch.empty_like(d)
+        check(_lib.lib().m3ae_dropout(_p(d), _p(dx), None, d.numel(), ctx.p, ctx.seed, _dt(d), _stream()), "m3ae_dropout")
+        return dx, None, None
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, next_dropout_seed())
+
+
+def dropout_keep_mask(n, p, seed, device="cuda"):
+    """uint8 keep-mask of the library's counter hash over linear indices 0..n-1 (tests)."""
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    check(_lib.lib().m3ae_dropout(None, None, _p(m), n, p, seed, F32, _stream()), "m3ae_dropout")
+    return m
 
 
 def selftest():

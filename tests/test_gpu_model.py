@@ -211,3 +211,36 @@ def test_tiny_t5_generative_head_against_reference_fixture(mode):
         assert abs(mine - r) <= tol * r + 1e-3 * tol * ref_total, (n, mine, r)
     m.store.adamw_step(max_steps=100, lr_factor=1.0)
     assert torch.isfinite(m.store.flat).all()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_training_mode_dropout_is_seeded_and_active(mode):
+    """model.train() with drop_rate = 0.1 (the reference's fine-tuning setting, m3ae/config.py:74): the step is
+    reproducible from `ops.set_dropout_seed`, differs across seeds and from eval(), and gradients stay finite."""
+    from m3ae_amd import ops
+    cfg = tiny_config(compute_dtype=mode, drop_rate=0.1)
+    m = build(cfg, torch.float32 if mode == "fp32" else torch.bfloat16)
+    b = to_dev(tiny_batch())
+    m.set_task()
+
+    def step(seed, train=True):
+        m.train(train)
+        m.store.zero_grad()
+        ops.set_dropout_seed(seed)
+        ret = m(b)
+        ret["vqa_loss"].backward()
+        return ret["vqa_loss"].item(), m.store.grad.clone()
+
+    l1, g1 = step(11)
+    l2, g2 = step(11)
+    l3, g3 = step(12)
+    le, ge = step(11, train=False)
+    assert np.isfinite(l1) and torch.isfinite(g1).all()
+    # same masks -> same step, up to the summation order of the fp32 atomics (loss reduction, split-K wgrad)
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and (g1 - g2).double().norm().item() <= 1e-5 * g1.double().norm().item()
+    assert abs(l1 - l3) > 1e-5 * abs(l1) and (g1 - g3).double().norm().item() > 1e-3 * g1.double().norm().item()
+    assert abs(l1 - le) > 1e-5 * abs(le)
+    # dropout perturbs, it does not destroy: loss within 20% of the eval loss, gradient norm within 2x
+    assert abs(l1 - le) < 0.2 * abs(le), (l1, le)
+    r = (g1.double().norm() / ge.double().norm()).item()
+    assert 0.5 < r < 2.0, r

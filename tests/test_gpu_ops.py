@@ -277,3 +277,169 @@ def test_adamw_matches_hf_semantics():
         O.adamw_step(pr, g.cpu() * 0.5, mr, vr, step, 1e-3, 0.01)
     close(p, pr, 1e-5, 1e-6, msg="adamw p")
     close(sh, pr, 1e-2, 1e-3, msg="adamw shadow")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# dropout (training mode; bert_model.py:334/:362/:440 and the RoBERTa embeddings).  The library's mask is a
+# counter hash of (seed, linear element index); the mask is exported and the op is checked against torch with
+# that exact mask, so these are deterministic parity tests, not statistical ones.
+# ----------------------------------------------------------------------------------------------------------
+def test_dropout_mask_statistics_and_determinism():
+    n, p = 1 << 20, 0.1
+    m1 = ops.dropout_keep_mask(n, p, 1234)
+    m2 = ops.dropout_keep_mask(n, p, 1234)
+    m3 = ops.dropout_keep_mask(n, p, 1235)
+    assert torch.equal(m1, m2)
+    assert (m1 != m3).float().mean().item() > 0.1
+    keep = m1.float().mean().item()
+    assert abs(keep - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n), keep
+    # neighbouring elements are uncorrelated (lag-1 autocorrelation of the keep bits)
+    f = m1.float() - keep
+    assert abs((f[1:] * f[:-1]).mean().item() / (p * (1 - p))) < 0.01
+    for dtype in (torch.float32, torch.bfloat16):
+        x = rnd(n, dtype=dtype, seed=40).requires_grad_(True)
+        ops.set_dropout_seed(7)
+        y = ops.dropout(x, p)
+        seed = ((7 << 32) | 1)
+        mk = ops.dropout_keep_mask(n, p, seed).float()
+        close(y, x.detach().float() * mk / (1 - p), 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-6, msg="dropout fwd")
+        y.backward(torch.ones_like(y))
+        close(x.grad, mk / (1 - p), 1e-2, 1e-6, msg="dropout bwd")
+    assert ops.dropout(x, p, training=False) is x and ops.dropout(x, 0.0) is x
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1154, 768, 768), (200, 136, 128), (4616, 768, 3072)])
+def test_gemm_epilogue_dropout_matches_exported_mask(dtype, M, N, K):
+    p, seed = 0.1, 0xABCDEF0123
+    x, w = rnd(M, K, dtype=dtype, seed=41), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=42)
+    b, r = rnd(N, seed=43), rnd(M, N, dtype=dtype, seed=44)
+    y, _ = ops.mm_nt(x, K, M, w, bias=b, residual=r, dropout=(p, seed))
+    mk = ops.dropout_keep_mask(M * N, p, seed).float().view(M, N)
+    ref = (x.float() @ w.float().t() + b) * mk / (1 - p) + r.float()
+    tol = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 2e-2)
+    close(y, ref, *tol, msg=f"gemm dropout path={ops.last_gemm_path()}")
+    # dropped elements are EXACTLY the residual
+    dropped = mk == 0
+    assert torch.equal(y[dropped], r[dropped])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd_drop_second_output(dtype):
+    M, D, p, seed = 1154, 768, 0.1, 99
+    x = rnd(M, D, dtype=dtype, seed=45)
+    ln = torch.nn.LayerNorm(D, eps=1e-12).to(dev())
+    ln.weight.data = 1 + 0.1 * rnd(D, seed=46)
+    ln.bias.data = 0.1 * rnd(D, seed=47)
+    for q in (ln.weight, ln.bias):
+        q.grad = torch.zeros_like(q)
+    _, mean, rstd = ops.ln_fwd_raw(x, ln)
+    dy = rnd(M, D, dtype=dtype, seed=48)
+    dx0 = ops.ln_bwd_raw(dy, x, ln, mean, rstd)
+    g0, b0 = ln.weight.grad.clone(), ln.bias.grad.clone()
+    ln.weight.grad.zero_(), ln.bias.grad.zero_()
+    dx, dxd = ops.ln_bwd_raw(dy, x, ln, mean, rstd, drop=(p, seed))
+    mk = ops.dropout_keep_mask(M * D, p, seed).float().view(M, D)
+    assert torch.equal(dx, dx0)
+    close(dxd, dx0.float() * mk / (1 - p), 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-7, msg="dx_drop")
+    close(ln.weight.grad, g0, 1e-5, 1e-4, msg="dgamma")
+    close(ln.bias.grad, b0, 1e-5, 1e-4, msg="dbeta")
+
+
+def _attn_ref_drop(q, k, v, H, mask, keep, p):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    dh = D // H
+    qh = q.view(B, Lq, H, dh).permute(0, 2, 1, 3)
+    kh = k.view(B, Lk, H, dh).permute(0, 2, 1, 3)
+    vh = v.view(B, Lk, H, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    pr = torch.softmax(s, dim=-1) * keep / (1 - p)  # nn.Dropout on attention_probs (bert_model.py:334)
+    return (pr @ vh).permute(0, 2, 1, 3).reshape(B, Lq, D)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Lq,Lk,masked", [(32, 32, True), (577, 577, False), (32, 577, False), (577, 32, True), (100, 45, True)])
+def test_attention_dropout_fwd_bwd_matches_exported_mask(dtype, Lq, Lk, masked):
+    B, H, dh, p, seed = 2, 3, 64, 0.1, 0x1234567
+    D = H * dh
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, device=dev())
+        mask[1, Lk // 2:] = -10000.0
+    keep = ops.dropout_keep_mask(B * H * Lq * Lk, p, seed).float().view(B, H, Lq, Lk)
+    do = rnd(B, Lq, D, dtype=dtype, seed=52)
+    if Lq != Lk:
+        q = rnd(B, Lq, D, dtype=dtype, seed=50).requires_grad_(True)
+        kv = rnd(B, Lk, 2 * D, dtype=dtype, seed=51).requires_grad_(True)
+        o = ops.cross_attention(q, kv, mask, H, (p, seed))
+        qr, kvr = q.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+        oref = _attn_ref_drop(qr, kvr[..., :D], kvr[..., D:], H, mask, keep, p)
+        leaves, rleaves = (q, kv), (qr, kvr)
+    else:
+        qkv = rnd(B, Lq, 3 * D, dtype=dtype, seed=53).requires_grad_(True)
+        o = ops.self_attention(qkv, mask, H, (p, seed))
+        qkvr = qkv.detach().float().requires_grad_(True)
+        oref = _attn_ref_drop(qkvr[..., :D], qkvr[..., D:2 * D], qkvr[..., 2 * D:], H, mask, keep, p)
+        leaves, rleaves = (qkv,), (qkvr,)
+    o.backward(do)
+    oref.backward(do.float())
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    close(o, oref, *tol, msg="attn dropout o")
+    for a, r in zip(leaves, rleaves):
+        close(a.grad, r.grad, tol[0], tol[1] * 2, msg="attn dropout grad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["cross", "self"])
+def test_fused_block_with_dropout_matches_op_level_composition(dtype, kind):
+    """Training-mode BertCrossLayer / RobertaLayer: the fused node (epilogue dropout, LN-backward second output,
+    in-kernel attention dropout) against the op-level composition with standalone dropout kernels on the same seeds."""
+    from types import SimpleNamespace
+    from m3ae_amd import synth
+    from m3ae_amd.modules.bert_model import BertCrossLayer, BertSelfLayer
+    from m3ae_amd.param_store import ParamStore
+    B, L, Lo, D, H = 2, 40, 101, 128, 2
+    layer = (BertCrossLayer(D, H, 4 * D, drop_rate=0.1) if kind == "cross" else BertSelfLayer(D, H, 4 * D, drop_rate=0.1))
+    synth.fill_deterministic(layer)
+    cfg = dict(learning_rate=1e-3, weight_decay=0.01, lr_multiplier_head=1, lr_multiplier_multi_modal=1)
+    store = ParamStore(layer, cfg, "cuda", dtype, weight_units=layer.weight_units)
+    layer.train()
+    h0 = rnd(B, L, D, dtype=dtype, seed=60)
+    e0 = rnd(B, Lo, D, dtype=dtype, seed=61)
+    mask = torch.zeros(B, L, device=dev())
+    mask[1, L - 7:] = -10000.0
+    dy = rnd(B, L, D, dtype=dtype, seed=62)
+    res = []
+    for fused in (True, False):
+        store.zero_grad()
+        ops.set_dropout_seed(321)
+        h, e = h0.clone().requires_grad_(True), e0.clone().requires_grad_(True)
+        if kind == "cross":
+            y = (layer if fused else layer.forward_unfused)(h, e, mask, None)
+        else:
+            y = (layer if fused else layer.forward_unfused)(h, mask)
+        y.backward(dy)
+        res.append(SimpleNamespace(y=y.detach().clone(), dh=h.grad.clone(), de=None if e.grad is None else e.grad.clone(),
+                                   g={n: q.grad.clone() for n, q in layer.named_parameters()}))
+    f, u = res
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    close(f.y, u.y, *tol, msg="y")
+    close(f.dh, u.dh, tol[0], tol[1] * 2, msg="dh")
+    if kind == "cross":
+        close(f.de, u.de, tol[0], tol[1] * 2, msg="d encoder states")
+    for n in f.g:
+        if n.endswith("key.bias"):  # identically zero in exact arithmetic (softmax shift invariance): pure rounding noise
+            continue
+        scale = u.g[n].abs().max().item() + 1e-12
+        close(f.g[n], u.g[n], tol[0] * 2, tol[1] * scale * 2, msg=n)
+    # dropout really happened: a different seed gives a different output, eval() gives the deterministic one
+    ops.set_dropout_seed(322)
+    y2 = layer(h0, e0, mask, None) if kind == "cross" else layer(h0, mask)
+    assert (y2.float() - f.y.float()).abs().max().item() > 0.05
+    layer.eval()
+    y3 = layer(h0, e0, mask, None) if kind == "cross" else layer(h0, mask)
+    y4 = layer(h0, e0, mask, None) if kind == "cross" else layer(h0, mask)
+    assert torch.equal(y3, y4)
