@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--t5", default="t5-small", help="t5-small (reference-faithful) | t5-base (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +109,9 @@ def main():
         model = M3AETransformerSS(cfg)
     synth.fill_deterministic(model)  # random-init weights of the named architecture (no checkpoints offline)
     model.finalize(dev, torch.bfloat16)
-    model.eval()  # dropout is not applied on this path
+    # the reference fine-tunes in train() mode with drop_rate = 0.1 (m3ae/config.py:74): dropout is part of the step.
+    # The T5 generative head's own dropout sites are not built yet, so that mode runs eval-mode semantics.
+    model.train(args.head == "cls" and not args.no_dropout)
     store = model.store
     reducer = FlatGradReducer(store).attach()
 
@@ -263,7 +266,8 @@ def main():
                              "teacher-forced decoder / tied LM head, top-4 encoder + top-4 decoder attention blocks "
                              "trainable (main_t5_m3ae.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "dropout": "off (eval-mode semantics)", "weights": "random-init (synthetic, deterministic)"},
+                       "dropout": ("p=0.1 in RoBERTa + fusion layers (train mode, as the reference)" if model.training
+                                   else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)"},
             "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1) if args.head == "cls" else None,
             "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
             if args.head == "cls" else None,
@@ -272,6 +276,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 runs the roofline / cpu_baseline legs alone; the others wait here, not in teardown
         dist.destroy_process_group()
 
 

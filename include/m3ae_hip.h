@@ -132,10 +132,13 @@ int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, c
                             const float* rstd, void* dx, void* dx_drop, float dropout_p, uint64_t dropout_seed,
                             float* dgamma, float* dbeta, float* workspace, int64_t M, int64_t D, int dtype,
                             void* stream);
-/* out = dropout(x) with the library's counter-hash mask over the linear element index (forward and backward are the
- * same map); keep_mask (uint8, optional) exports the mask for tests. */
-int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t n, float p, uint64_t seed, int dtype,
-                 void* stream);
+/* out = dropout(x) on a dense [rows][cols] array with the library's counter-hash mask (forward and backward are
+ * the same map).  Every dropout site of the library -- this call, the GEMM epilogue (rows = M, cols = N), the
+ * LayerNorm backward second output, and attention probabilities (rows = (b*H + h)*Lq + q, cols = Lk) -- uses the mask
+ * index row * ld + col with ld = cols rounded up to a multiple of 4, so a mask exported here (keep_mask, uint8
+ * [rows][cols], optional) is the mask those kernels apply for the same (p, seed). */
+int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t rows, int64_t cols, float p, uint64_t seed,
+                 int dtype, void* stream);
 
 /* out[n] (+)= sum_m x[m][n]  (bias gradients; x has row stride ldx elements). */
 int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,

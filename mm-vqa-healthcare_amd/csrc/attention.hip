@@ -40,9 +40,10 @@ struct AttnArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     float* delta;
     float* d_pos_bias;
-    DropState drop;  // attention-probability dropout (bert_model.py:334)
+    DropState drop;  // attention-probability dropout (bert_model.py:334); mask index ((b H + h) Lq + q) * ld(Lk) + k
     int has_drop;
 };
+DEVINL int64_t drop_ldk(int64_t Lk) { return (Lk + 3) & ~(int64_t)3; }
 
 DEVINL f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
@@ -201,8 +202,12 @@ DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1,
     l += lsum;
     if (a.has_drop) {  // the normaliser keeps every key; only the P that multiplies V is dropped (and rescaled)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            s[reg] = drop_apply(a.drop, drop_row + (uint64_t)(key0 + crow(reg, h)), s[reg]);
+        for (int r4 = 0; r4 < 4; ++r4) {  // registers 4 r4 .. 4 r4 + 3 = keys key0 + 8 r4 + 4 h + (0..3): one hash
+            float x4[4] = {s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]};
+            drop_apply4(a.drop, drop_row + (uint64_t)(key0 + 8 * r4 + 4 * h), x4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[4 * r4 + t] = x4[t];
+        }
     }
 }
 
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
             const int64_t key0 = (int64_t)kt * 32;
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
-                const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi[n]) * a.Lk);
+                const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi[n]) * drop_ldk(a.Lk));
                 if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
                 else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
             }
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 
     f32x16 g0 = zero16(), g1 = zero16();
     const int nkt = (int)((a.Lk + 31) / 32);
-    const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi) * a.Lk);
+    const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi) * drop_ldk(a.Lk));
     s16x8 kreg = coop_load(kbase, a.k_sl, 0, a.Lk, t);
     s16x8 vreg = coop_load(vbase, a.v_sl, 0, a.Lk, t);
     put_row_img(lds, kreg, t);
@@ -713,6 +718,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
+            uint32_t dh4[4] = {0u, 0u, 0u, 0u};
+            if (a.has_drop) {  // registers 4 r4 .. 4 r4 + 3 hold 4 consecutive keys: one hash per group
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) dh4[r4] = drop_hash(a.drop, (drow + (uint64_t)(kt * 32 + 8 * r4 + 4 * h)) >> 2);
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int64_t key = (int64_t)kt * 32 + crow(reg, h);
@@ -727,7 +737,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
                 if (CAUSAL) valid = valid && key <= qi;
                 const float p = valid ? fast_exp2(x - lse) : 0.f;
                 float dpe = dp[reg];
-                if (a.has_drop) dpe = drop_apply(a.drop, drow + (uint64_t)key, dpe);  // dP wrt the un-dropped P
+                if (a.has_drop)  // dP wrt the un-dropped P
+                    dpe = rotr32(dh4[reg >> 2], 8u * (reg & 3)) >= a.drop.thr ? dpe * a.drop.inv_keep : 0.f;
                 const float ds = p * (dpe - dlt);
                 if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
                 s[reg] = ds;
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
                 const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
                 float pd = pv, dpe = dp[reg];
                 if (a.has_drop) {
-                    const uint64_t di = (uint64_t)(((b * a.H + head) * a.Lq + (qq < a.Lq ? qq : a.Lq - 1)) * a.Lk + krow);
+                    const uint64_t di = (uint64_t)(((b * a.H + head) * a.Lq + (qq < a.Lq ? qq : a.Lq - 1)) * drop_ldk(a.Lk) + krow);
                     const bool keep = drop_keep(a.drop, di);
                     pd = keep ? pv * a.drop.inv_keep : 0.f;    // the P that multiplied V in the forward pass
                     dpe = keep ? dpe * a.drop.inv_keep : 0.f;  // dP wrt the un-dropped P
@@ -1027,8 +1038,8 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
     float* S = (float*)d.workspace;
     int rc = attn_f32_scores(d, S, s);
     if (rc) return rc;
-    if (d.dropout_p > 0.f &&  // P is [B][H][Lq][Lk]: the linear index is the bf16 kernels' mask index
-        (rc = m3ae_dropout(S, S, nullptr, d.B * d.H * d.Lq * d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+    if (d.dropout_p > 0.f &&  // P is [B H Lq][Lk]: rows x cols of the same mask index the bf16 kernels use
+        (rc = m3ae_dropout(S, S, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
         return rc;
     const int64_t QK = d.Lq * d.Lk;
     m3ae_gemm_desc g = bgemm(d);
@@ -1068,7 +1079,7 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     float* dS = P + d.B * d.H * QK;
     int rc = attn_f32_scores(d, P, s);
     if (rc) return rc;
-    if (drop && (rc = m3ae_dropout(P, P, nullptr, d.B * d.H * QK, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+    if (drop && (rc = m3ae_dropout(P, P, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
         return rc;  // dV below needs the dropped P that multiplied V in the forward pass
     // dP = dO . V^T
     m3ae_gemm_desc g = bgemm(d);
@@ -1087,7 +1098,7 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     const int64_t rows = d.B * d.H * d.Lq;
     if (drop) {  // the softmax backward needs the un-dropped P and dP wrt it
         if ((rc = attn_f32_scores(d, P, s))) return rc;
-        if ((rc = m3ae_dropout(dS, dS, nullptr, d.B * d.H * QK, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+        if ((rc = m3ae_dropout(dS, dS, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
             return rc;
     }
     hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, P, dS, rows, d.Lk);

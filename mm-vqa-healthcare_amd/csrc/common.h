@@ -109,8 +109,13 @@ DEVINL float act_bwd_fast(float x, int act) {
 }
 
 // ---- dropout: counter-based keep mask ---------------------------------------------------------------------
-// keep(seed, idx) = lowbias32(lo32(idx) ^ lowbias32(lo32(seed) + hi32(idx) * 0x9E3779B9 + hi32(seed))) >= p * 2^32.
-// Stateless, so forward and backward regenerate the same mask from (seed, element index) with ~10 integer ops.
+// Every dropout site is a 2-D array [rows][cols]; element (row, col) has the index idx = row * ld + col with
+// ld = cols rounded up to a multiple of 4 (drop_ld).  Four consecutive indices share ONE 32-bit hash
+//     h(g) = lowbias32((lo32(g) ^ lo32(seed)) + hi32(g) * 0x9E3779B9 + hi32(seed)),  g = idx >> 2,
+// and element j = idx & 3 keeps iff rotr(h, 8 j) >= p * 2^32: each rotation is uniform on 32 bits (exact keep
+// probability), and the four decisions read four different top bytes of h.  Stateless: forward and backward
+// regenerate the same mask from (seed, idx).  A lane that owns 4 aligned consecutive elements (GEMM / LayerNorm
+// epilogues, the attention score fragments) pays one hash (2 integer multiplies) per 4 elements.
 DEVINL uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -132,11 +137,21 @@ DEVINL DropState make_drop_dev(float p, uint64_t seed) {  // same as make_drop, 
     d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }
+__host__ __device__ static inline int64_t drop_ld(int64_t cols) { return (cols + 3) & ~(int64_t)3; }
+DEVINL uint32_t drop_hash(const DropState& d, uint64_t group) {
+    return lowbias32((((uint32_t)group) ^ d.key_lo) + (uint32_t)(group >> 32) * 0x9E3779B9U + d.key_hi);
+}
+DEVINL uint32_t rotr32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, r); }
 DEVINL bool drop_keep(const DropState& d, uint64_t idx) {
-    const uint32_t k = lowbias32(d.key_lo + (uint32_t)(idx >> 32) * 0x9E3779B9U + d.key_hi);
-    return lowbias32((uint32_t)idx ^ k) >= d.thr;
+    return rotr32(drop_hash(d, idx >> 2), 8u * ((uint32_t)idx & 3u)) >= d.thr;
 }
 DEVINL float drop_apply(const DropState& d, uint64_t idx, float x) { return drop_keep(d, idx) ? x * d.inv_keep : 0.f; }
+// x[0..3] are the elements idx4 .. idx4 + 3, idx4 % 4 == 0
+DEVINL void drop_apply4(const DropState& d, uint64_t idx4, float* x) {
+    const uint32_t h = drop_hash(d, idx4 >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = rotr32(h, 8u * j) >= d.thr ? x[j] * d.inv_keep : 0.f;
+}
 
 DEVINL float wave_sum(float v) {
 #pragma unroll

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
             if (d.bias) x += d.bias[gn];
             if (P) Elem<TC>::st(P + off, x);
             x = act_fwd(x, d.act);
-            if (d.dropout_p > 0.f) x = drop_apply(drop, (uint64_t)(gm * d.N + gn), x);
+            if (d.dropout_p > 0.f) x = drop_apply(drop, (uint64_t)(gm * drop_ld(d.N) + gn), x);
             if (R) x += Elem<TC>::ld(R + off);
             if (X) x *= act_bwd(Elem<TC>::ld(X + off), d.dact);
             if (d.accumulate) x += Elem<TC>::ld(C + off);

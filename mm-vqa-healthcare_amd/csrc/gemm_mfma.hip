@@ -129,9 +129,8 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = act_fwd_fast(x[t], act);
     }
-    if (a.has_drop) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = drop_apply(a.drop, (uint64_t)(m * a.N + n + t), x[t]);
+    if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
+        drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);  // N % 4 == 0 on this path: ld = N
     }
     if (a.residual) {
         Vec4<TC>::ld((const TC*)a.residual + off, y);
@@ -188,9 +187,9 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = act_fwd_fast(x[t], act);
     }
-    if (a.has_drop) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = drop_apply(a.drop, (uint64_t)(m * a.N + n + t), x[t]);
+    if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
+        drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);
+        drop_apply4(a.drop, (uint64_t)(m * a.N + n + 4), x + 4);
     }
     if (a.residual) {
         Vec8<TC>::ld((const TC*)a.residual + off, y);
@@ -564,6 +563,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.drop = make_drop(d.dropout_p, d.dropout_seed);
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
+    if (a.has_drop) return launch_nt_v<EPI_ANY>(a, s);
     if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);
     if (!has_dact && d.act == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_QGELU>(a, s);
     if (!has_act && d.dact == M3AE_ACT_GELU) return launch_nt_v<EPI_DGELU>(a, s);

@@ -311,9 +311,10 @@ __global__ void act_bwd_kernel(const T* dy, const T* x, T* dx, int64_t n, int ac
         Elem<T>::st(dx + i, Elem<T>::ld(dy + i) * act_bwd(Elem<T>::ld(x + i), act));
 }
 template <typename T>
-__global__ void dropout_kernel(const T* x, T* out, uint8_t* keep, int64_t n, DropState ds) {
+__global__ void dropout_kernel(const T* x, T* out, uint8_t* keep, int64_t n, int64_t cols, int64_t ld, DropState ds) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const bool k = drop_keep(ds, (uint64_t)i);
+        const int64_t r = i / cols;
+        const bool k = drop_keep(ds, (uint64_t)(r * ld + (i - r * cols)));
         if (out) Elem<T>::st(out + i, k ? Elem<T>::ld(x + i) * ds.inv_keep : 0.f);
         if (keep) keep[i] = k ? 1 : 0;
     }
@@ -497,13 +498,14 @@ extern "C" int m3ae_act_bwd(const void* dy, const void* x_pre, void* dx, int64_t
     DT_SWITCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)dy, (const T*)x_pre, (T*)dx, n, act));
     return hip_launch_status();
 }
-extern "C" int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t n, float p, uint64_t seed, int dtype,
-                            void* stream) {
-    if (n <= 0 || p < 0.f || p >= 1.f || (!out && !keep_mask) || (out && !x)) return M3AE_ERR_ARG;
+extern "C" int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t rows, int64_t cols, float p,
+                            uint64_t seed, int dtype, void* stream) {
+    if (rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f || (!out && !keep_mask) || (out && !x)) return M3AE_ERR_ARG;
+    const int64_t n = rows * cols;
     hipStream_t s = (hipStream_t)stream;
     const DropState ds = make_drop(p, seed);
     DT_SWITCH(dtype, hipLaunchKernelGGL(dropout_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)x, (T*)out,
-                                        keep_mask, n, ds));
+                                        keep_mask, n, cols, drop_ld(cols), ds));
     return hip_launch_status();
 }
 

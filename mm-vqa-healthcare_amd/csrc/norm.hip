@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
                 if (dx_drop) {
                     float od[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) od[t] = drop_apply(drop, (uint64_t)(row * D + ch * 4 + t), o[t]);
+                    for (int t = 0; t < 4; ++t) od[t] = o[t];
+                    drop_apply4(drop, (uint64_t)(row * D + ch * 4), od);  // D % 4 == 0: ld = D
                     st4<T>(dx_drop + row * D + ch * 4, od);
                 }
                 if (dx_add) {

@@ -49,7 +49,7 @@ _SIGS = {
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
     "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp, vp, vp, i64, i64, C.c_int, vp]),
-    "m3ae_dropout": (C.c_int, [vp, vp, vp, i64, f32, C.c_uint64, C.c_int, vp]),
+    "m3ae_dropout": (C.c_int, [vp, vp, vp, i64, i64, f32, C.c_uint64, C.c_int, vp]),
     "m3ae_colsum": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),

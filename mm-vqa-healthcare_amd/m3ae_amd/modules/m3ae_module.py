@@ -8,8 +8,9 @@ runs in hand-written gfx950 kernels (libm3ae_hip.so) -- there is no PyTorch-op f
 
 Differences that are deliberate (DESIGN.md): weights are never downloaded (architecture comes from the config);
 `finalize(device)` moves the parameters into the flat MI355X layout (ParamStore) and must be called before the
-first forward; attention probabilities are not materialised (`output_attentions` is rejected); eval-mode /
-`drop_rate=0` semantics (dropout is not applied).
+first forward; attention probabilities are not materialised (`output_attentions` is rejected); dropout
+(`module.training`, RoBERTa p = 0.1, fusion layers p = `drop_rate`) uses the library's counter-hash masks fused into
+the kernels (seeded by `ops.set_dropout_seed`), not torch's Philox stream.
 """
 import torch
 import torch.nn as nn

@@ -532,7 +532,7 @@ class CrossAttnFn(torch.autograd.Function):
 
 
 def self_attention(qkv, key_mask, heads, dropout=None):
-    """dropout = (p, seed): attention-probability dropout (mask index ((b*H + h)*Lq + q)*Lk + k)."""
+    """dropout = (p, seed): attention-probability dropout (mask rows (b*H + h)*Lq + q, columns k)."""
     return SelfAttnFn.apply(qkv, key_mask, heads, dropout)
 
 
@@ -1060,7 +1060,9 @@ class DropoutFn(torch.autograd.Function):
     def forward(ctx, x, p, seed):
         xc = x.contiguous()
         y = torch.empty_like(xc)
-        check(_lib.lib().m3ae_dropout(_p(xc), _p(y), None, xc.numel(), p, seed, _dt(xc), _stream()), "m3ae_dropout")
+        cols = xc.shape[-1]
+        check(_lib.lib().m3ae_dropout(_p(xc), _p(y), None, xc.numel() // cols, cols, p, seed, _dt(xc), _stream()),
+              "m3ae_dropout")
         ctx.p, ctx.seed = p, seed
         return y
 
@@ -1068,7 +1070,9 @@ class DropoutFn(torch.autograd.Function):
     def backward(ctx, dy):
         d = dy.contiguous()
         dx = torch.empty_like(d)
-        check(_lib.lib().m3ae_dropout(_p(d), _p(dx), None, d.numel(), ctx.p, ctx.seed, _dt(d), _stream()), "m3ae_dropout")
+        cols = d.shape[-1]
+        check(_lib.lib().m3ae_dropout(_p(d), _p(dx), None, d.numel() // cols, cols, ctx.p, ctx.seed, _dt(d), _stream()),
+              "m3ae_dropout")
         return dx, None, None
 
 
@@ -1078,10 +1082,11 @@ def dropout(x, p, training=True):
     return DropoutFn.apply(x, p, next_dropout_seed())
 
 
-def dropout_keep_mask(n, p, seed, device="cuda"):
-    """uint8 keep-mask of the library's counter hash over linear indices 0..n-1 (tests)."""
-    m = torch.empty(n, dtype=torch.uint8, device=device)
-    check(_lib.lib().m3ae_dropout(None, None, _p(m), n, p, seed, F32, _stream()), "m3ae_dropout")
+def dropout_keep_mask(rows, cols, p, seed, device="cuda"):
+    """uint8 [rows, cols] keep-mask of the library's counter hash: the mask every dropout site applies for (p, seed)
+    on a [rows, cols] array -- GEMM epilogue (M, N), LayerNorm backward (M, D), attention ((b*H + h)*Lq + q, Lk)."""
+    m = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    check(_lib.lib().m3ae_dropout(None, None, _p(m), rows, cols, p, seed, F32, _stream()), "m3ae_dropout")
     return m
 
 

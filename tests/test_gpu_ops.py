@@ -285,23 +285,29 @@ def test_adamw_matches_hf_semantics():
 # that exact mask, so these are deterministic parity tests, not statistical ones.
 # ----------------------------------------------------------------------------------------------------------
 def test_dropout_mask_statistics_and_determinism():
-    n, p = 1 << 20, 0.1
-    m1 = ops.dropout_keep_mask(n, p, 1234)
-    m2 = ops.dropout_keep_mask(n, p, 1234)
-    m3 = ops.dropout_keep_mask(n, p, 1235)
-    assert torch.equal(m1, m2)
-    assert (m1 != m3).float().mean().item() > 0.1
-    keep = m1.float().mean().item()
-    assert abs(keep - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n), keep
-    # neighbouring elements are uncorrelated (lag-1 autocorrelation of the keep bits)
-    f = m1.float() - keep
-    assert abs((f[1:] * f[:-1]).mean().item() / (p * (1 - p))) < 0.01
+    p = 0.1
+    for rows, cols in ((1024, 1024), (1733, 577)):  # 577: odd row length (the index stride is padded to 580)
+        n = rows * cols
+        m1 = ops.dropout_keep_mask(rows, cols, p, 1234)
+        m2 = ops.dropout_keep_mask(rows, cols, p, 1234)
+        m3 = ops.dropout_keep_mask(rows, cols, p, 1235)
+        assert torch.equal(m1, m2)
+        assert (m1 != m3).float().mean().item() > 0.1
+        keep = m1.float().mean().item()
+        assert abs(keep - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n), keep
+        # four neighbours share one hash (a different byte each): keep bits must still be uncorrelated at lags
+        # 1..4 along a row and between rows
+        f = m1.float() - keep
+        for lag in (1, 2, 3, 4):
+            assert abs((f[:, lag:] * f[:, :-lag]).mean().item() / (p * (1 - p))) < 0.01, lag
+        assert abs((f[1:] * f[:-1]).mean().item() / (p * (1 - p))) < 0.01
+    rows, cols = 1024, 1024
     for dtype in (torch.float32, torch.bfloat16):
-        x = rnd(n, dtype=dtype, seed=40).requires_grad_(True)
+        x = rnd(rows, cols, dtype=dtype, seed=40).requires_grad_(True)
         ops.set_dropout_seed(7)
         y = ops.dropout(x, p)
         seed = ((7 << 32) | 1)
-        mk = ops.dropout_keep_mask(n, p, seed).float()
+        mk = ops.dropout_keep_mask(rows, cols, p, seed).float()
         close(y, x.detach().float() * mk / (1 - p), 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-6, msg="dropout fwd")
         y.backward(torch.ones_like(y))
         close(x.grad, mk / (1 - p), 1e-2, 1e-6, msg="dropout bwd")
@@ -315,7 +321,7 @@ def test_gemm_epilogue_dropout_matches_exported_mask(dtype, M, N, K):
     x, w = rnd(M, K, dtype=dtype, seed=41), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=42)
     b, r = rnd(N, seed=43), rnd(M, N, dtype=dtype, seed=44)
     y, _ = ops.mm_nt(x, K, M, w, bias=b, residual=r, dropout=(p, seed))
-    mk = ops.dropout_keep_mask(M * N, p, seed).float().view(M, N)
+    mk = ops.dropout_keep_mask(M, N, p, seed).float()
     ref = (x.float() @ w.float().t() + b) * mk / (1 - p) + r.float()
     tol = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 2e-2)
     close(y, ref, *tol, msg=f"gemm dropout path={ops.last_gemm_path()}")
@@ -339,7 +345,7 @@ def test_layernorm_bwd_drop_second_output(dtype):
     g0, b0 = ln.weight.grad.clone(), ln.bias.grad.clone()
     ln.weight.grad.zero_(), ln.bias.grad.zero_()
     dx, dxd = ops.ln_bwd_raw(dy, x, ln, mean, rstd, drop=(p, seed))
-    mk = ops.dropout_keep_mask(M * D, p, seed).float().view(M, D)
+    mk = ops.dropout_keep_mask(M, D, p, seed).float()
     assert torch.equal(dx, dx0)
     close(dxd, dx0.float() * mk / (1 - p), 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-7, msg="dx_drop")
     close(ln.weight.grad, g0, 1e-5, 1e-4, msg="dgamma")
@@ -369,7 +375,7 @@ def test_attention_dropout_fwd_bwd_matches_exported_mask(dtype, Lq, Lk, masked):
     if masked:
         mask = torch.zeros(B, Lk, device=dev())
         mask[1, Lk // 2:] = -10000.0
-    keep = ops.dropout_keep_mask(B * H * Lq * Lk, p, seed).float().view(B, H, Lq, Lk)
+    keep = ops.dropout_keep_mask(B * H * Lq, Lk, p, seed).float().view(B, H, Lq, Lk)
     do = rnd(B, Lq, D, dtype=dtype, seed=52)
     if Lq != Lk:
         q = rnd(B, Lq, D, dtype=dtype, seed=50).requires_grad_(True)
