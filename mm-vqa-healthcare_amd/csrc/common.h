@@ -75,15 +75,14 @@ DEVINL float act_bwd(float x, int act) {
 // The same exp(-x^2/2) term serves the Gaussian pdf of the derivative.  Parity (fp32) mode never uses these.
 DEVINL void gelu_terms_fast(float x, float& cdf, float& pdf) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    const float e = __expf(-z * z);  // = exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));  // raw v_rcp_f32 (1 ulp), not an IEEE division
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // = exp(-x^2 / 2)
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * e;
-    const float erf_x = x < 0.f ? -erf_abs : erf_abs;
-    cdf = 0.5f * (1.0f + erf_x);
+    const float half_erfc = 0.5f * poly * t * e;  // 0.5 erfc(|x| / sqrt 2)
+    cdf = x < 0.f ? half_erfc : 1.0f - half_erfc;
     pdf = 0.39894228040143267794f * e;
 }
 DEVINL float act_fwd_fast(float x, int act) {
@@ -92,7 +91,7 @@ DEVINL float act_fwd_fast(float x, int act) {
         gelu_terms_fast(x, cdf, pdf);
         return x * cdf;
     }
-    if (act == M3AE_ACT_QUICKGELU) return x * __frcp_rn(1.0f + __expf(-1.702f * x));
+    if (act == M3AE_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546695959f * x));
     return act_fwd(x, act);
 }
 DEVINL float act_bwd_fast(float x, int act) {
@@ -102,10 +101,59 @@ DEVINL float act_bwd_fast(float x, int act) {
         return fmaf(x, pdf, cdf);
     }
     if (act == M3AE_ACT_QUICKGELU) {
-        const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546695959f * x));
         return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     return act_bwd(x, act);
+}
+
+// Two elements at a time: the FMA / multiply chain compiles to packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32:
+// two lanes-worth of work per issue slot); the two transcendentals per element stay scalar-per-lane.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVINL f32x2 splat2(float v) { return (f32x2){v, v}; }
+DEVINL void gelu_terms_fast2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 den = __builtin_elementwise_fma(splat2(0.3275911f * 0.70710678118654752440f), ax, splat2(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 xx = x * x * splat2(-0.72134752044448170368f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+    f32x2 poly = __builtin_elementwise_fma(splat2(1.061405429f), t, splat2(-1.453152027f));
+    poly = __builtin_elementwise_fma(poly, t, splat2(1.421413741f));
+    poly = __builtin_elementwise_fma(poly, t, splat2(-0.284496736f));
+    poly = __builtin_elementwise_fma(poly, t, splat2(0.254829592f));
+    const f32x2 h = splat2(0.5f) * poly * t * e;
+    const f32x2 om = splat2(1.0f) - h;
+    cdf = (f32x2){x[0] < 0.f ? h[0] : om[0], x[1] < 0.f ? h[1] : om[1]};
+    pdf = splat2(0.39894228040143267794f) * e;
+}
+// y[0..n) = act(x[0..n)) / act'(x[0..n)), n even
+template <int N> DEVINL void act_fwd_fast_n(float* x, int act) {
+    if (act == M3AE_ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < N; t += 2) {
+            f32x2 c, p, v = {x[t], x[t + 1]};
+            gelu_terms_fast2(v, c, p);
+            v = v * c;
+            x[t] = v[0]; x[t + 1] = v[1];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < N; ++t) x[t] = act_fwd_fast(x[t], act);
+    }
+}
+template <int N> DEVINL void act_bwd_mul_fast_n(float* x, const float* pre, int act) {  // x *= act'(pre)
+    if (act == M3AE_ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < N; t += 2) {
+            f32x2 c, p, u = {pre[t], pre[t + 1]}, v = {x[t], x[t + 1]};
+            gelu_terms_fast2(u, c, p);
+            v = v * __builtin_elementwise_fma(u, p, c);
+            x[t] = v[0]; x[t + 1] = v[1];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < N; ++t) x[t] *= act_bwd_fast(pre[t], act);
+    }
 }
 
 // ---- dropout: counter-based keep mask ---------------------------------------------------------------------

@@ -126,8 +126,7 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
     if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
         if (a.preact) Vec4<TC>::st((TC*)a.preact + off, x);
         const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = act_fwd_fast(x[t], act);
+        act_fwd_fast_n<4>(x, act);
     }
     if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);  // N % 4 == 0 on this path: ld = N
@@ -141,8 +140,7 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
         if (a.dact_aux) {
             const int dact = EPI == EPI_DGELU ? M3AE_ACT_GELU : (EPI == EPI_DQGELU ? M3AE_ACT_QUICKGELU : a.dact);
             Vec4<TC>::ld((const TC*)a.dact_aux + off, y);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] *= act_bwd_fast(y[t], dact);
+            act_bwd_mul_fast_n<4>(x, y, dact);
         }
     }
     if (a.accumulate) {
@@ -155,53 +153,58 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
 
 template <typename TC> struct Vec8;
 template <> struct Vec8<float> {
+    static DEVINL void unpack(const u32x4&, float*) {}  // fp32 C tiles are never prefetched
     static DEVINL void ld(const float* p, float* x) { Vec4<float>::ld(p, x); Vec4<float>::ld(p + 4, x + 4); }
     static DEVINL void st(float* p, const float* x) { Vec4<float>::st(p, x); Vec4<float>::st(p + 4, x + 4); }
 };
 template <> struct Vec8<bf16_t> {
-    static DEVINL void ld(const bf16_t* p, float* x) {
-        const u32x4 v = *(const u32x4*)p;
+    static DEVINL void unpack(const u32x4& v, float* x) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { x[2 * t] = __uint_as_float(v[t] << 16); x[2 * t + 1] = __uint_as_float(v[t] & 0xffff0000u); }
     }
+    static DEVINL void ld(const bf16_t* p, float* x) { unpack(*(const u32x4*)p, x); }
     static DEVINL void st(bf16_t* p, const float* x) {
         *(u32x4*)p = (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
     }
 };
 
 // Fused epilogue on 8 consecutive n of row m: 16-byte bf16 (2 x 16-byte fp32) accesses, 8 lanes = one 128-B line.
+// bias8: the 8 bias values of columns n .. n + 7 (preloaded once per wave); pre: the 16 bytes of the residual (or,
+// for the dact classes, of dact_aux) at (m, n .. n + 7), fetched before the LDS transposes so that the epilogue pays
+// the global-load latency once per wave instead of once per 32-row pass (bf16 C only; nullptr = load here).
 template <typename TC, int EPI>
-DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x) {
+DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const float* bias8, bool has_pre,
+                      const u32x4 pre) {
+    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU);
     const int64_t off = m * a.ldc + n;
     float y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] *= a.alpha;
     if (a.bias) {
-        Vec8<float>::ld(a.bias + n, y);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] += y[t];
+        for (int t = 0; t < 8; ++t) x[t] += bias8[t];
     }
     if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
         if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
         const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = act_fwd_fast(x[t], act);
+        act_fwd_fast_n<8>(x, act);
     }
     if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);
         drop_apply4(a.drop, (uint64_t)(m * a.N + n + 4), x + 4);
     }
     if (a.residual) {
-        Vec8<TC>::ld((const TC*)a.residual + off, y);
+        if (has_pre && !PRE_IS_AUX) Vec8<TC>::unpack(pre, y);
+        else Vec8<TC>::ld((const TC*)a.residual + off, y);
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += y[t];
     }
     if (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_ANY) {
         if (a.dact_aux) {
             const int dact = EPI == EPI_DGELU ? M3AE_ACT_GELU : (EPI == EPI_DQGELU ? M3AE_ACT_QUICKGELU : a.dact);
-            Vec8<TC>::ld((const TC*)a.dact_aux + off, y);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) x[t] *= act_bwd_fast(y[t], dact);
+            if (has_pre && PRE_IS_AUX) Vec8<TC>::unpack(pre, y);
+            else Vec8<TC>::ld((const TC*)a.dact_aux + off, y);
+            act_bwd_mul_fast_n<8>(x, y, dact);
         }
     }
     if (a.accumulate) {
@@ -220,7 +223,29 @@ template <typename TC, int EPI, int MI>
 DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int64_t m_base, int64_t n_base,
                           f32x4 (&acc)[MI][4]) {
     constexpr int LDW = 68;
+    constexpr bool BF = sizeof(TC) == 2;
+    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU);
     float* t = (float*)smem + wave * 32 * LDW;
+    const int64_t ncol = n_base + (lane & 7) * 8;
+    // everything the epilogue reads from global memory is requested up front: the wave waits for DRAM once
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.bias && ncol < a.N) Vec8<float>::ld(a.bias + ncol, bias8);
+    const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
+    const bool has_pre = BF && src != nullptr;
+    u32x4 pre[MI / 2][4];
+#pragma unroll
+    for (int half = 0; half < MI / 2; ++half)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) pre[half][pass] = (u32x4){0u, 0u, 0u, 0u};
+    if (has_pre) {
+#pragma unroll
+        for (int half = 0; half < MI / 2; ++half)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int64_t m = m_base + 32 * half + pass * 8 + (lane >> 3);
+                if (m < a.M && ncol < a.N) pre[half][pass] = *(const u32x4*)(src + m * a.ldc + ncol);
+            }
+    }
 #pragma unroll
     for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
@@ -236,7 +261,7 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
             const f32x4 v1 = *(const f32x4*)(t + row * LDW + col + 4);
             float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const int64_t m = m_base + 32 * half + row, n = n_base + col;
-            if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x);
+            if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x, bias8, has_pre, pre[half][pass]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -537,11 +562,11 @@ template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
         const bool big = a.M >= 4096 && a.N >= 512;
-        if (big && EPI == EPI_PLAIN) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
-        if (big) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
+        if (big) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
     if (g_nt_variant == 5) return launch_nt_t<128, 128, 32, 2, 64, EPI>(a, s);  // 34 KiB LDS: 4 workgroups / CU
+    if (g_nt_variant == 6 && a.M > 128) return launch_nt_t<256, 128, 32, 3, 128, EPI>(a, s);  // 72 KiB LDS: 2 workgroups / CU
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
     if (g_nt_variant == 3 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
     if (g_nt_variant == 2 && a.M > 128) return launch_nt_t<256, 128, 32, 2, 128, EPI>(a, s);
