@@ -58,6 +58,20 @@ DEVINL unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
+// Tile order inside the (XCD-contiguous) id range: column tiles in groups of 4, row-major inside a group.  An XCD then
+// works against <= 4 column tiles of B (<= 1.5 MiB at K = 768: resident in its 4-MiB L2) while A streams, instead of
+// cycling through all of B for every row block (N = 3072: B = 4.7 MiB thrashed the L2 -- 7x the algorithmic reads, PMC).
+DEVINL void nt_tile_coords(unsigned wg, unsigned tiles_m, unsigned tiles_n, unsigned& tm, unsigned& tn) {
+    constexpr unsigned GC = 4;
+    const unsigned per_group = tiles_m * GC;
+    const unsigned g = wg / per_group;
+    const unsigned first = g * GC;
+    const unsigned gc = tiles_n - first < GC ? tiles_n - first : GC;
+    const unsigned local = wg - g * per_group;
+    tm = local / gc;
+    tn = first + local % gc;
+}
+
 DEVINL void glds16(const void* src, char* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_uniform, 16, 0, 0);
 }
@@ -283,9 +297,10 @@ __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
     const unsigned tiles_n = (unsigned)((a.N + BN_ - 1) / BN_);
-    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(wg / tiles_n) * BM_;
-    const int64_t n0 = (int64_t)(wg % tiles_n) * BN_;
+    unsigned tm, tn;
+    nt_tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM_;
+    const int64_t n0 = (int64_t)tn * BN_;
 
     f32x4 acc[MI][4];
 #pragma unroll
@@ -551,6 +566,151 @@ static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
     return hip_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// NT "ping-pong" kernel: 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each), 32-deep reduction chunks in a 4-slot LDS
+// ring (128 KiB).  Each chunk is consumed in TWO phases (rows 0-63 / 64-127 of the wave's sub-tile: 16 MFMAs each);
+// a phase is  [LDS fragment reads + 2 LDS-DMA issues] s_barrier [16 MFMAs] s_barrier.  The two wave rows (wr = 0 / 1:
+// one wave of each per SIMD) run staggered by one barrier, so on every SIMD one wave is in its MFMA cluster while the
+// other fetches fragments and issues DMA -- the MFMA pipe never waits for LDS.
+//
+// Ring schedule (phase p = 2c / 2c+1 works on chunk c in slot c & 3; loads are issued in the order B(0) A(0) B(1) A(1) ...):
+//   phase 2c   issues B(c+3) into slot (c-1)&3 -- B(c-1) was last read in phase 2c-2 (two phases earlier: every wave's
+//              reads were retired by an lgkmcnt(0) at least two barriers ago, stagger included);
+//   phase 2c+1 issues A(c+3)                   -- A(c-1) was last read in phase 2c-1;
+//   phase 2c+1 waits (counted vmcnt: the 8 loads of chunks c+2, c+3 stay in flight) for chunk c+1 BEFORE its first
+//              barrier; chunk c+1 is first read in phase 2c+2, i.e. after a barrier every wave passed post-wait.
+// ---------------------------------------------------------------------------------------------------------
+#define PP_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
+    constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned tiles_n = (unsigned)((a.N + 255) / 256);
+    unsigned tm, tn;
+    nt_tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, tm, tn);
+    const int64_t m0 = (int64_t)tm * 256;
+    const int64_t n0 = (int64_t)tn * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nc = (int)(a.K / CK);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c < nc) {
+            nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, smem + c * SLOT + A_BYTES, wave, lane);
+            nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, smem + c * SLOT, wave, lane);
+        }
+    }
+    if (nc >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nc == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_FENCE();
+    __builtin_amdgcn_s_barrier();  // chunk 0 is in LDS for every wave
+    PP_FENCE();
+    if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }  // stagger the second wave row by one barrier
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int c = 0; c < nc; ++c) {
+        const char* At = smem + (c & 3) * SLOT;
+        const char* Bt = At + A_BYTES;
+        char* nxt = smem + ((c + 3) & 3) * SLOT;
+        const bool more = c + 3 < nc;
+        s16x8 bfr[4], af[4];
+        // ---------------- phase 2c: rows 0..63 of the wave's sub-tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<CK>(Bt, wc * 64 + j * 16 + frow, fchunk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + i * 16 + frow, fchunk);
+        if (more) nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES, wave, lane);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        // ---------------- phase 2c + 1: rows 64..127 (the B fragments stay in registers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
+        if (more) nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt, wave, lane);
+        {
+            const int rem = nc - 1 - c;  // chunks after this one; chunk c + 1 must have landed before the next phase
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+    }
+    if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }  // re-align: every wave has executed 4 nc + 2 barriers
+    // all fragment reads are retired and no DMA is outstanding (vmcnt(0) in the last odd phase): the ring is free
+
+    if (a.rows_epi) {
+        if (a.c_f32) epilogue_rows<float, EPI, 8>(a, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, acc);
+        else epilogue_rows<bf16_t, EPI, 8>(a, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, acc);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
+            if (n >= a.N) continue;
+            if (a.c_f32) epilogue4<float, EPI>(a, m, n, acc[i][j]);
+            else epilogue4<bf16_t, EPI>(a, m, n, acc[i][j]);
+        }
+    }
+}
+
+template <int EPI>
+static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
+    constexpr int lds = 4 * (256 + 256) * 32 * 2;  // 128 KiB ring; the epilogue slabs (8 x 8704 B) reuse it
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, s, a);
+    return hip_launch_status();
+}
+
 // variants (m3ae_set_tuning key 0):
 //   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU
 //   1: 256x128 tile, BK 64, 3 stages, 8 waves x (64x64)   -- 144 KiB LDS, 1 workgroup / CU, counted vmcnt
@@ -558,13 +718,18 @@ static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
 //      and LDS-read traffic per FLOP (12 fragment reads per 32 MFMAs)
 //   3: 256x256 tile, BK 32, 4 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU: half the L1->LDS bytes/FLOP
 //   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU
+//   6: 256x128 tile, BK 32, 3 stages, 4 waves x (128x64)  -- 72 KiB LDS, 2 workgroups / CU
+//   7: 256x256 tile, 32-deep chunks in a 4-slot ring, 8 waves in two staggered rows (ping-pong, gemm_nt_pp_kernel)
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
         const bool big = a.M >= 4096 && a.N >= 512;
-        if (big) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
+        // ping-pong kernel (variant 7): 1232 / 1340 TF/s at 4096^3 / 8192^3, +3..10 % over the 2-stage kernel on the
+        // path's own shapes (profiles/r01_gemm_shapes.log)
+        if (big) return launch_nt_pp<EPI>(a, s);
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
+    if (g_nt_variant == 7 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);  // ping-pong 8-phase
     if (g_nt_variant == 5) return launch_nt_t<128, 128, 32, 2, 64, EPI>(a, s);  // 34 KiB LDS: 4 workgroups / CU
     if (g_nt_variant == 6 && a.M > 128) return launch_nt_t<256, 128, 32, 3, 128, EPI>(a, s);  // 72 KiB LDS: 2 workgroups / CU
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);

@@ -1,0 +1,43 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the counters do
+not fit one pass).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies
+128-B requests at 64 B -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores and float atomics.  Both are in KiB.
+usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [kernel-substring ...]"""
+import collections
+import csv
+import re
+import sys
+
+
+def load(path, counter):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            n = re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"])
+            n = re.sub(r"^void ", "", n).split("(")[0]
+            d[n][0] += 1
+            d[n][1] += float(row["Counter_Value"])
+    return d
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    pats = sys.argv[3:]
+    rows = []
+    for n in sorted(set(fetch) | set(write)):
+        if pats and not any(p in n for p in pats):
+            continue
+        cf, f = fetch.get(n, (0, 0.0))
+        cw, w = write.get(n, (0, 0.0))
+        c = max(cf, cw, 1)
+        rd, wr = 2.0 * f * 1024 / c, w * 1024 / c
+        rows.append((rd + wr, n, c, rd, wr))
+    print(f"{'kernel':100s} {'launches':>8s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'total MB':>10s}")
+    for tot, n, c, rd, wr in sorted(rows, reverse=True)[:40]:
+        print(f"{n[:100]:100s} {c:8d} {rd / 1e6:15.2f} {wr / 1e6:16.2f} {tot / 1e6:10.2f}")
+
+
+if __name__ == "__main__":
+    main()
