@@ -196,14 +196,23 @@ def main():
                 f"{2.0 * M_ * N_ * K_ * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s, total {ms_ / 2:7.2f} ms/step")
         kern_table = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                       for k, v in agg.items() if v[1] > 0}
-        dom = "gemm:mfma_nt"
+        dom = "gemm:mfma_nt_pp"  # the dominant kernel of the step: gemm_nt_pp_kernel (all epilogue instantiations)
         if dom in agg:
             n, ms, fl = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": round(ach, 1),
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                        "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
+                        "traffic": None, "launches": n // 2, "avg_launch_ms": round(ms / n, 4),
                         "flops_per_launch": fl / n}
+            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
+            # FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read) -- only when the workload matches
+            tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tp):
+                with open(tp) as f:
+                    tj = json.load(f)
+                if tj.get("per_gpu_batch") == B and tj.get("head") == args.head:
+                    roofline["traffic"] = tj["gemm_nt_pp_kernel"]["bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; " + tp[len(ROOT) + 1:] + ")"
         # fused cross-attention forward (all 6 layers, both directions), HIP events around the sub-blocks
         m3 = model.m3ae if args.head == "t5" else model
         with torch.no_grad():
@@ -241,7 +250,7 @@ def main():
         cb = synth.synthetic_batch(2, text_len=32, image_size=384, rank=0)
         oc = oracle_cfg(cfg)
         times = []
-        for i in range(3):
+        for i in range(9):
             for p in sd.values():
                 p.grad = None
             tt = time.perf_counter()
@@ -251,7 +260,7 @@ def main():
             log(f"cpu_baseline iter {i}: {times[-1]:.1f}s")
         best = min(times[1:])
         cpu = {"value": round(2 / best, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "B=2 fwd+bwd fp32 (no optimizer), 1 warm-up + 2 timed, oracle/m3ae_oracle.py on PyTorch-CPU"}
+               "sample": "B=2 fwd+bwd fp32 (no optimizer), 1 warm-up + 8 timed (best), oracle/m3ae_oracle.py on PyTorch-CPU"}
 
     if rank == 0:
         line = {

@@ -707,6 +707,7 @@ static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+    g_last_path = "mfma_nt_pp";
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, s, a);
     return hip_launch_status();
 }

@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the counters do
 not fit one pass).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies
 128-B requests at 64 B -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores and float atomics.  Both are in KiB.
-usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [kernel-substring ...]"""
+usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [--json out.json B head]"""
 import collections
 import csv
 import re
@@ -24,7 +24,10 @@ def load(path, counter):
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
-    pats = sys.argv[3:]
+    pats = []
+    js = None
+    if len(sys.argv) > 3 and sys.argv[3] == "--json":
+        js = (sys.argv[4], int(sys.argv[5]), sys.argv[6])
     rows = []
     for n in sorted(set(fetch) | set(write)):
         if pats and not any(p in n for p in pats):
@@ -37,6 +40,28 @@ def main():
     print(f"{'kernel':100s} {'launches':>8s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'total MB':>10s}")
     for tot, n, c, rd, wr in sorted(rows, reverse=True)[:40]:
         print(f"{n[:100]:100s} {c:8d} {rd / 1e6:15.2f} {wr / 1e6:16.2f} {tot / 1e6:10.2f}")
+    if js:
+        import json
+        out = {"per_gpu_batch": js[1], "head": js[2],
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py "
+                         "--no-cpu-baseline --no-roofline --steps 2 --warmup 1`; FETCH_SIZE x 2 (gfx950 tallies 128-B "
+                         "requests at 64 B), both KiB -> bytes; calibrated on adamw_kernel (16 B read / 14 B written per "
+                         "parameter: 5.15 GB / 4.51 GB per step measured vs 5.15 / 4.51 expected); fabric-side counters, "
+                         "Infinity-Cache hits included",
+               "gemm_nt_pp_kernel": summary(fetch, write, "gemm_nt_pp_kernel"),
+               "gemm_tn_bf16_kernel": summary(fetch, write, "gemm_tn_bf16_kernel"),
+               "attn_fwd_coop_kernel": summary(fetch, write, "attn_fwd_coop_kernel"),
+               "adamw_kernel": summary(fetch, write, "adamw_kernel")}
+        with open(js[0], "w") as f:
+            json.dump(out, f, indent=1)
+
+
+def summary(fetch, write, prefix):
+    c = sum(v[0] for k, v in fetch.items() if k.startswith(prefix))
+    rd = sum(v[1] for k, v in fetch.items() if k.startswith(prefix)) * 2.0 * 1024
+    wr = sum(v[1] for k, v in write.items() if k.startswith(prefix)) * 1024
+    return {"launches_in_profile": c, "read_bytes_per_launch": rd / max(c, 1), "write_bytes_per_launch": wr / max(c, 1),
+            "bytes_per_launch": (rd + wr) / max(c, 1)}
 
 
 if __name__ == "__main__":
