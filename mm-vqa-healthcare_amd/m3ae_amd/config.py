@@ -105,9 +105,16 @@ def compose(*parts, **overrides):
 
 
 def parse_cli(argv):
-    """Parse the sacred grammar of run_scripts/*.sh: `with k=v ... named_config ... k=v`."""
+    """Parse the sacred grammar of run_scripts/*.sh: `with k=v ... named_config ... k=v`.  As in sacred, named configs
+    apply first (left to right) and explicit `k=v` updates win over them wherever they stand on the command line
+    (finetune_m3ae.sh passes `max_epoch=70` BEFORE `task_finetune_vqa_vqa_rad`, whose own max_epoch is 20)."""
     args = [a for a in argv if a != "with"]
     cfg = copy.deepcopy(DEFAULTS)
+    for a in args:
+        if "=" not in a:
+            if a not in NAMED:
+                raise KeyError(f"unknown named config {a!r}")
+            cfg.update(copy.deepcopy(NAMED[a]))
     for a in args:
         if "=" in a:
             k, v = a.split("=", 1)
@@ -116,10 +123,6 @@ def parse_cli(argv):
             except (ValueError, SyntaxError):
                 pass
             cfg[k] = v
-        elif a in NAMED:
-            cfg.update(copy.deepcopy(NAMED[a]))
-        else:
-            raise KeyError(f"unknown named config {a!r}")
     return resolve_arch(cfg)
 
 

@@ -4,6 +4,8 @@ against (a) the CPU oracle on the same seeded inputs and (b) the committed refer
 Tolerances (stated per north_star): parity mode (fp32) logits rtol 1e-3 vs the reference fixtures, gradient norms
 rtol 2e-3; perf mode (bf16 storage, fp32 accumulate / statistics / softmax) is held to bf16-appropriate bounds:
 logits atol 0.05 (|logits| <= 0.7), loss rtol 2e-3, global grad-norm rtol 3e-2."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,42 @@ def test_training_mode_dropout_is_seeded_and_active(mode):
     assert abs(l1 - le) < 0.2 * abs(le), (l1, le)
     r = (g1.double().norm() / ge.double().norm()).item()
     assert 0.5 < r < 2.0, r
+
+
+def test_trainer_shim_fit_checkpoint_resume(tmp_path):
+    """the sacred-free entry point on the run_scripts grammar -- accumulation, schedule, validation,
+    checkpoints with the reference's state_dict names, resume."""
+    from m3ae_amd import trainer
+    from m3ae_amd.modules import state_dict_spec
+    tiny = ("image_size=64 hidden_size=128 num_heads=2 num_top_layer=2 input_image_embed_size=128 "
+            "input_text_embed_size=128 vocab_size=1000 vit_width=128 vit_layers=3 text_hidden=128 text_layers=2 "
+            "text_heads=2 text_inter=512").split()
+    argv = (["with", "data_root=synthetic", "num_gpus=1", "num_nodes=1", "task_finetune_vqa_vqa_rad", "clip16",
+             "text_roberta", "per_gpu_batchsize=4", "batch_size=8", "max_steps=6", "learning_rate=0.0005",
+             "synthetic_train_samples=32", "synthetic_val_samples=8", f"log_dir={tmp_path}", "seed=3"] + tiny)
+    out = trainer.run(argv)
+    assert out["global_step"] == 6
+    hist = out["history"]
+    assert hist[0][0] == 1 and np.isfinite([h[1] for h in hist]).all()
+    cfg = trainer.config_mod.parse_cli(argv)
+    run_dir = os.path.join(str(tmp_path), f'{cfg["exp_name"]}-seed3-from_', "checkpoints")
+    ck = torch.load(os.path.join(run_dir, "last.ckpt"), map_location="cpu", weights_only=False)
+    spec = state_dict_spec(cfg)
+    assert set(ck["state_dict"]) == set(spec) and all(tuple(ck["state_dict"][k].shape) == tuple(spec[k]) for k in spec)
+    assert ck["global_step"] == 6 and "optimizer_flat" not in ck  # finetune runs save weights only (main.py:42)
+    # the saved weights reproduce the trained model's logits in a fresh module
+    m = M3AETransformerSS(cfg)
+    m.load_state_dict(ck["state_dict"], strict=False)
+    m.finalize("cuda", torch.bfloat16)
+    m.eval()
+    m.set_task()
+    b = to_dev(synth.synthetic_batch(4, text_len=32, image_size=64, vocab_size=1000, rank=0))
+    l1 = m(b)["vqa_logits"].float()
+    assert torch.isfinite(l1).all()
+    # training moved the weights away from the initial ones
+    m0 = build(cfg, torch.bfloat16)
+    m0.set_task()
+    assert (m0(b)["vqa_logits"].float() - l1).abs().max().item() > 1e-3
+    # resume: the step counter (and with it the LR schedule) continues
+    out2 = trainer.run(argv[:-len(tiny)] + tiny + [f"resume_from={os.path.join(run_dir, 'last.ckpt')}", "max_steps=8"])
+    assert out2["global_step"] == 8

@@ -86,3 +86,25 @@ def test_synthetic_batch_schema_and_determinism():
     w1 = synth.det_normal("some.weight", (8, 8), std=0.02)
     w2 = synth.det_normal("some.weight", (8, 8), std=0.02)
     assert torch.equal(w1, w2)
+
+
+def test_trainer_plan_follows_reference_main():
+    """grad accumulation and step budget as main.py:49-52 derives them from the run_scripts arguments."""
+    from m3ae_amd import trainer
+    # the argument list of run_scripts/finetune_m3ae.sh (data, not code), reduced to the keys that matter here
+    argv = ("with data_root=data/finetune_arrows/ num_workers=0 max_epoch=70 learning_rate=0.00001 batch_size=64 "
+            "num_gpus=1 num_nodes=1 task_finetune_vqa_vqa_rad per_gpu_batchsize=8 clip16 text_roberta image_size=384 "
+            "tokenizer=downloaded/roberta-base").split()
+    cfg = config.parse_cli(argv)
+    assert trainer.grad_steps_of(cfg, 1) == 8 and trainer.grad_steps_of(cfg, 8) == 1
+    p = trainer.plan(cfg, 1, 3064)
+    assert p["grad_steps"] == 8 and p["max_steps"] == 1000 and p["max_epochs"] == 1000  # named config: max_steps=1000
+    assert p["micro_per_epoch"] == 383 and p["steps_per_epoch"] == 47
+    cfg2 = config.parse_cli(argv + ["max_steps=-1"])
+    p2 = trainer.plan(cfg2, 2, 3064)
+    assert p2["grad_steps"] == 4 and p2["max_epochs"] == 70 and p2["max_steps"] == 70 * (3064 // 16 // 4)
+    # VQA score (my_metrics.py:66-79): soft target at the arg-max logit
+    logits = torch.tensor([[0.1, 2.0, -1.0], [3.0, 0.0, 0.5]])
+    targets = torch.tensor([[0.0, 0.6, 1.0], [0.0, 1.0, 0.0]])
+    s, n = trainer.vqa_score(logits, targets)
+    assert n == 2 and abs(s.item() - 0.6) < 1e-6
