@@ -539,7 +539,7 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int m3ae_attn_set_coop(int v);
-static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : 2;
+static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : -1;
 static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
@@ -762,6 +762,177 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     return launch_nt_v<EPI_ANY>(a, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// TN "ping-pong" kernel (wgrad): the structure of gemm_nt_pp_kernel with transposing fragment reads.  256 x 256 output
+// tile, 8 waves (2 x 4, 128 x 64 each), 32 reduction rows per chunk ([32][256] bf16 image of each operand, 16 KiB) in a
+// 4-slot ring; two phases per chunk (output rows 0-63 / 64-127 of the wave), the two wave rows staggered by one
+// barrier; B(c+3) / A(c+3) issued in phases 2c / 2c+1, counted vmcnt(8) in the odd phase.  Split over the reduction
+// with fp32 atomics; the bias gradient rides on a ones-fragment MFMA in the first column tile's waves.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
+    constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const unsigned tiles_n = (unsigned)(a.N / 256);
+    const unsigned tiles = (unsigned)(a.M / 256) * tiles_n;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tile_id = wg % tiles, split = wg / tiles;
+    const int64_t m0 = (int64_t)(tile_id / tiles_n) * 256;
+    const int64_t n0 = (int64_t)(tile_id % tiles_n) * 256;
+    const int64_t r_begin = (int64_t)split * a.k_chunk;
+    int64_t r_end = r_begin + a.k_chunk;
+    if (r_end > a.K) r_end = a.K;
+    if (r_begin >= r_end) return;  // whole workgroup: uniform
+    const int nc = (int)((r_end - r_begin + CK - 1) / CK);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = a.a_rowsum != nullptr && n0 == 0 && wc == 0;
+    f32x4 rsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rsum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c < nc) {
+            const int64_t r0 = r_begin + (int64_t)c * CK;
+            tn_stage<256, 2, NW>(a.B, a.ldb, r0, r_end, n0, smem + c * SLOT + A_BYTES, wave, lane);
+            tn_stage<256, 2, NW>(a.A, a.lda, r0, r_end, m0, smem + c * SLOT, wave, lane);
+        }
+    }
+    if (nc >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nc == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_FENCE();
+    __builtin_amdgcn_s_barrier();
+    PP_FENCE();
+    if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+
+    for (int c = 0; c < nc; ++c) {
+        const char* At = smem + (c & 3) * SLOT;
+        const char* Bt = At + A_BYTES;
+        char* nxt = smem + ((c + 3) & 3) * SLOT;
+        const bool more = c + 3 < nc;
+        const int64_t r3 = r_begin + (int64_t)(c + 3) * CK;
+        s16x8 bfr[4], af[4];
+        // ---------------- phase 2c: output rows 0..63 of the wave's sub-tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tn_frag<256>(Bt, 0, wc * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = tn_frag<256>(At, 0, wr * 128 + i * 16, lane);
+        if (more) tn_stage<256, 2, NW>(a.B, a.ldb, r3, r_end, n0, nxt + A_BYTES, wave, lane);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        if (do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), rsum[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        // ---------------- phase 2c + 1: output rows 64..127 (the B fragments stay in registers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = tn_frag<256>(At, 0, wr * 128 + 64 + i * 16, lane);
+        if (more) tn_stage<256, 2, NW>(a.A, a.lda, r3, r_end, m0, nxt, wave, lane);
+        {
+            const int rem = nc - 1 - c;
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[4 + i][j], 0, 0, 0);
+        if (do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rsum[4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), rsum[4 + i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+    }
+    if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(a.a_rowsum + m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + r, rsum[i][r]);
+    }
+    // lane holds D[n1 = .. + 4 * (lane >> 4) + reg][n2 = .. + (lane & 15)]
+    float* C = (float*)a.C;
+    const bool atomic = a.splits > 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n1 = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + r;
+                const int64_t n2 = n0 + wc * 64 + j * 16 + (lane & 15);
+                float* p = C + n1 * a.ldc + n2;
+                const float x = acc[i][j][r] * a.alpha;
+                if (atomic) atomicAdd(p, x);
+                else if (a.accumulate) *p += x;
+                else *p = x;
+            }
+}
+
+static int launch_tn_pp(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
+    constexpr int lds = 4 * (256 + 256) * 32 * 2;
+    const int64_t tiles = (d.M / 256) * (d.N / 256);
+    const int64_t ksteps = cdiv(d.K, 64);
+    int64_t splits = 256 / tiles;  // one workgroup per CU, one round
+    if (splits > ksteps / 8) splits = ksteps / 8;
+    if (splits < 1) splits = 1;
+    if (!d.accumulate) splits = 1;
+    const int64_t steps_per = cdiv(ksteps, splits);
+    a.k_chunk = steps_per * 64;
+    splits = cdiv(ksteps, steps_per);
+    a.splits = (int)splits;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(512), lds, s, a);
+    return hip_launch_status();
+}
+
 template <int BM_, int BN_, int WM, int BKR, int NST>
 static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
     constexpr int lds = NST * (BM_ + BN_) * BKR * 2;
@@ -797,6 +968,13 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K;
     a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
     // variant 1: 256x256 tile, 8 waves x (128x64): half the operand re-read traffic of the 128x128 tile
+    const bool pp_ok = d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096;
+    if (g_tn_variant == 5 && pp_ok) return launch_tn_pp(a, d, s);
+    if (g_tn_variant < 0) {  // auto (default), measured (profiles/r01_gemm_shapes.log): the ping-pong kernel wins on long
+        // reductions (+2..10 % at 147712 rows) and, from 32768 rows, on the large outputs only
+        if (pp_ok && (d.K >= 65536 || (d.K >= 32768 && d.M * d.N >= 768 * 3072))) return launch_tn_pp(a, d, s);
+        return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);
+    }
     if (g_tn_variant == 1 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096) return launch_tn_t<256, 256, 128, 64, 2>(a, d, s);
     if (g_tn_variant == 2) return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);  // 32 KiB LDS: 3 workgroups / CU
     if (g_tn_variant == 3) return launch_tn_t<128, 128, 64, 32, 4>(a, d, s);  // 4-stage ring of 32-row steps, counted vmcnt

@@ -449,3 +449,24 @@ def test_fused_block_with_dropout_matches_op_level_composition(dtype, kind):
     y3 = layer(h0, e0, mask, None) if kind == "cross" else layer(h0, mask)
     y4 = layer(h0, e0, mask, None) if kind == "cross" else layer(h0, mask)
     assert torch.equal(y3, y4)
+
+
+@pytest.mark.parametrize("M,N,K", [(4616, 256, 512), (9000, 768, 768), (36928, 768, 3072), (5000, 1536, 256), (4100, 512, 768)])
+def test_gemm_wgrad_tn_pingpong_variant(M, N, K):
+    """TN variant 5 (gemm_tn_pp_kernel: 256x256 tile, staggered wave rows) incl. ragged reduction tails and the fused
+    bias gradient; repeated to screen the ring for races (every run must agree with the fp32 reference)."""
+    from m3ae_amd import _lib
+    _lib.lib().m3ae_set_tuning(1, 5)
+    try:
+        dy, x = rnd(M, N, dtype=torch.bfloat16, seed=70), rnd(M, K, dtype=torch.bfloat16, seed=71)
+        ref = dy.float().t() @ x.float()
+        refb = dy.float().sum(0)
+        for it in range(6):
+            g = torch.zeros(N, K, dtype=torch.float32, device=dev())
+            db = torch.zeros(N, dtype=torch.float32, device=dev())
+            ops.gemm(dy, 1, N, x, K, 1, g, K, N, K, M, accumulate=True, a_rowsum=db)
+            assert ops.last_gemm_path() == "mfma_tn"
+            close(g, ref, 1e-4, 1e-3 * math.sqrt(M), msg=f"wgrad pp iter {it}")
+            close(db, refb, 1e-4, 1e-3 * math.sqrt(M), msg=f"bias grad pp iter {it}")
+    finally:
+        _lib.lib().m3ae_set_tuning(1, -1)
