@@ -157,7 +157,7 @@ DEVINL f32x16 zero16() {
 // branch-free loop body; only the LAST key tile pays for bounds handling.
 struct Flags { bool mask, bias, causal; };
 
-template <bool MASK, bool BIAS, bool CAUSAL, bool LAST>
+template <bool MASK, bool BIAS, bool CAUSAL, bool LAST, bool DROP = false>
 DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1, const AttnArgs& a, const float* mrow,
                           const float* brow, int64_t key0, int64_t qi, int h, uint64_t drop_row = 0) {
     // log2-domain scores, additive mask / bias, bounds; online softmax update of (m, l, o)
@@ -200,7 +200,7 @@ DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1,
         lsum += p;
     }
     l += lsum;
-    if (a.has_drop) {  // the normaliser keeps every key; only the P that multiplies V is dropped (and rescaled)
+    if (DROP) {  // the normaliser keeps every key; only the P that multiplies V is dropped (and rescaled)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {  // registers 4 r4 .. 4 r4 + 3 = keys key0 + 8 r4 + 4 h + (0..3): one hash
             float x4[4] = {s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]};
@@ -548,7 +548,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) 
 // ceiling).  Two LDS images per streamed operand where both kinds of MFMA fragment are needed:
 //   row image  [32][128 B], chunk ^= (row >> 1) & 7  -> conflict-free ds_read_b128 row fragments
 //   tr  image  [32][192 B]                           -> conflict-free ds_read_b64_tr_b16 transposed fragments
-// Double-buffered, one __syncthreads() per streamed tile.
+// Double-buffered LDS images, ONE raw s_barrier per streamed tile; the global fetch runs TWO tiles ahead in registers
+// (tile t + 2 is requested before tile t is computed and written to LDS at the end of tile t + 1), so a tile's
+// L2 / HBM latency has a whole tile of MFMA + softmax work to hide behind.  __syncthreads() is not used in the loops:
+// its implicit vmcnt(0) would drain that prefetch at every tile.
 // =========================================================================================================
 constexpr int RIMG = 32 * 128;  // row image bytes
 
@@ -558,6 +561,11 @@ DEVINL s16x8 coop_load(const bf16_t* base, int64_t sl, int64_t row0, int64_t nro
     int64_t row = row0 + (t >> 3);
     row = row < nrows ? row : nrows - 1;
     return *(const s16x8*)(base + row * sl + (t & 7) * 8);
+}
+DEVINL void coop_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this lane's LDS image writes (and fragment reads) retired
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 DEVINL void put_row_img(char* img, s16x8 v, int t) {
     const int row = t >> 3, ch = t & 7;
@@ -585,8 +593,10 @@ DEVINL AttnBlock attn_block() {
     return o;
 }
 
-template <int NQ, bool MASK, bool BIAS, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
+// DROP (attention-probability dropout) is a template parameter: a run-time test per score element would split the
+// unrolled softmax into 16 basic blocks and fence the MFMA / VALU interleave for the eval-mode instances too.
+template <int NQ, bool MASK, bool BIAS, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP) ? 4 : 2) void attn_fwd_coop_kernel(AttnArgs a) {
     constexpr int BUF = RIMG + TILE_LDS;  // K row image + V tr image
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
@@ -624,12 +634,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
     s16x8 vreg = coop_load(vbase, a.v_sl, 0, a.Lk, t);
     put_row_img(lds, kreg, t);
     put_tr_img(lds + RIMG, vreg, t);
-    __syncthreads();
+    if (nkt > 1) {
+        kreg = coop_load(kbase, a.k_sl, 32, a.Lk, t);
+        vreg = coop_load(vbase, a.v_sl, 32, a.Lk, t);
+    }
+    coop_barrier();
     for (int kt = 0; kt < nkt; ++kt) {
         const bool last = kt + 1 == nkt;
-        if (!last) {
-            kreg = coop_load(kbase, a.k_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
-            vreg = coop_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+        s16x8 kreg2 = kreg, vreg2 = vreg;
+        if (kt + 2 < nkt) {
+            kreg2 = coop_load(kbase, a.k_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
+            vreg2 = coop_load(vbase, a.v_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
         }
         const char* kimg = lds + (kt & 1) * BUF;
         const char* vimg = kimg + RIMG;
@@ -648,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi[n]) * drop_ldk(a.Lk));
-                if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
-                else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
+                if (last) score_to_prob<MASK, BIAS, CAUSAL, true, DROP>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
+                else score_to_prob<MASK, BIAS, CAUSAL, false, DROP>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h, drow);
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -667,7 +682,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
             put_row_img(nb, kreg, t);
             put_tr_img(nb + RIMG, vreg, t);
         }
-        __syncthreads();
+        kreg = kreg2; vreg = vreg2;
+        coop_barrier();
     }
     if (!active) return;
 #pragma unroll
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_coop_kernel(AttnArgs a) {
     }
 }
 
-template <bool MASK, bool BIAS, bool CAUSAL>
+template <bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
     constexpr int BUF = RIMG + TILE_LDS + RIMG;  // K row image, K tr image, V row image
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
@@ -718,12 +734,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
     put_row_img(lds, kreg, t);
     put_tr_img(lds + RIMG, kreg, t);
     put_row_img(lds + RIMG + TILE_LDS, vreg, t);
-    __syncthreads();
+    if (nkt > 1) {
+        kreg = coop_load(kbase, a.k_sl, 32, a.Lk, t);
+        vreg = coop_load(vbase, a.v_sl, 32, a.Lk, t);
+    }
+    coop_barrier();
     for (int kt = 0; kt < nkt; ++kt) {
         const bool last = kt + 1 == nkt;
-        if (!last) {
-            kreg = coop_load(kbase, a.k_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
-            vreg = coop_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+        s16x8 kreg2 = kreg, vreg2 = vreg;
+        if (kt + 2 < nkt) {
+            kreg2 = coop_load(kbase, a.k_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
+            vreg2 = coop_load(vbase, a.v_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
         }
         const char* kimg = lds + (kt & 1) * BUF;
         const char* ktr = kimg + RIMG;
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
             uint32_t dh4[4] = {0u, 0u, 0u, 0u};
-            if (a.has_drop) {  // registers 4 r4 .. 4 r4 + 3 hold 4 consecutive keys: one hash per group
+            if (DROP) {  // registers 4 r4 .. 4 r4 + 3 hold 4 consecutive keys: one hash per group
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) dh4[r4] = drop_hash(a.drop, (drow + (uint64_t)(kt * 32 + 8 * r4 + 4 * h)) >> 2);
             }
@@ -756,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
                 if (CAUSAL) valid = valid && key <= qi;
                 const float p = valid ? fast_exp2(x - lse) : 0.f;
                 float dpe = dp[reg];
-                if (a.has_drop)  // dP wrt the un-dropped P
+                if (DROP)  // dP wrt the un-dropped P
                     dpe = rotr32(dh4[reg >> 2], 8u * (reg & 3)) >= a.drop.thr ? dpe * a.drop.inv_keep : 0.f;
                 const float ds = p * (dpe - dlt);
                 if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
@@ -775,12 +796,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             put_tr_img(nb + RIMG, kreg, t);
             put_row_img(nb + RIMG + TILE_LDS, vreg, t);
         }
-        __syncthreads();
+        kreg = kreg2; vreg = vreg2;
+        coop_barrier();
     }
     if (active && qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
 }
 
-template <bool MASK, bool BIAS, bool CAUSAL>
+template <bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) {
     constexpr int BUF = 2 * (RIMG + TILE_LDS);  // Q row, Q tr, dO row, dO tr
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
@@ -818,12 +840,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     put_tr_img(lds + RIMG, qreg, t);
     put_row_img(lds + RIMG + TILE_LDS, doreg, t);
     put_tr_img(lds + 2 * RIMG + TILE_LDS, doreg, t);
-    __syncthreads();
+    if (nqt > 1) {
+        qreg = coop_load(qbase, a.q_sl, 32, a.Lq, t);
+        doreg = coop_load(dobase, a.o_sl, 32, a.Lq, t);
+    }
+    coop_barrier();
     for (int qt = 0; qt < nqt; ++qt) {
         const bool last = qt + 1 == nqt;
-        if (!last) {
-            qreg = coop_load(qbase, a.q_sl, (int64_t)(qt + 1) * 32, a.Lq, t);
-            doreg = coop_load(dobase, a.o_sl, (int64_t)(qt + 1) * 32, a.Lq, t);
+        s16x8 qreg2 = qreg, doreg2 = doreg;
+        if (qt + 2 < nqt) {
+            qreg2 = coop_load(qbase, a.q_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
+            doreg2 = coop_load(dobase, a.o_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
         }
         const char* qimg = lds + (qt & 1) * BUF;
         const char* qtr = qimg + RIMG;
@@ -855,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
                 if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
                 const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
                 float pd = pv, dpe = dp[reg];
-                if (a.has_drop) {
+                if (DROP) {
                     const uint64_t di = (uint64_t)(((b * a.H + head) * a.Lq + (qq < a.Lq ? qq : a.Lq - 1)) * drop_ldk(a.Lk) + krow);
                     const bool keep = drop_keep(a.drop, di);
                     pd = keep ? pv * a.drop.inv_keep : 0.f;    // the P that multiplied V in the forward pass
@@ -883,13 +910,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
             put_row_img(nb + RIMG + TILE_LDS, doreg, t);
             put_tr_img(nb + 2 * RIMG + TILE_LDS, doreg, t);
         }
-        __syncthreads();
+        qreg = qreg2; doreg = doreg2;
+        coop_barrier();
     }
     if (active && key_ok) {
         store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
         store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
     }
 }
+
+// coop kernels: mask / bias / causal as below plus the dropout instances (BERT layers only: no bias, not causal)
+#define ATTN_DISPATCH_COOP(rc, KERNEL, grid, s, a, ...)                                                                  \
+    do {                                                                                                                 \
+        const int f = (a.key_mask ? 1 : 0) | (a.pos_bias ? 2 : 0) | (a.causal ? 4 : 0);                                  \
+        if (a.has_drop) {                                                                                                \
+            if (f == 0) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, false, true>), grid, dim3(256), 0, s, a);   \
+            else if (f == 1) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, false, true>), grid, dim3(256), 0, s, a); \
+            else rc = M3AE_ERR_UNSUPPORTED;                                                                              \
+            break;                                                                                                       \
+        }                                                                                                                \
+        switch (f) {                                                                                                     \
+            case 0: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, false, false>), grid, dim3(256), 0, s, a); break; \
+            case 1: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, false, false>), grid, dim3(256), 0, s, a); break;  \
+            case 2: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, false, false>), grid, dim3(256), 0, s, a); break;  \
+            case 3: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, false, false>), grid, dim3(256), 0, s, a); break;   \
+            case 4: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, true, false>), grid, dim3(256), 0, s, a); break;  \
+            case 5: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, true, false>), grid, dim3(256), 0, s, a); break;   \
+            case 6: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, true, false>), grid, dim3(256), 0, s, a); break;   \
+            default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, true, false>), grid, dim3(256), 0, s, a); break;   \
+        }                                                                                                                \
+    } while (0)
 
 // flag dispatch (mask / bias / causal are wave-uniform launch properties)
 #define ATTN_DISPATCH3(KERNEL, grid, s, a, ...)                                                                       \
@@ -1016,6 +1066,9 @@ bool bf16_layout_ok(const m3ae_attn_desc& d, bool bwd) {
 }  // namespace
 
 static int g_attn_coop = getenv("M3AE_ATTN_COOP") ? atoi(getenv("M3AE_ATTN_COOP")) : 1;
+// 1 (default): 32 query rows per wave everywhere (577 = 18 x 32 + 1: finer blocks waste less, occupancy 4: 188 -> 135 us
+// at B = 64); 2: 64 rows per wave on long sequences
+static int g_attn_nq = getenv("M3AE_ATTN_NQ") ? atoi(getenv("M3AE_ATTN_NQ")) : 1;
 int m3ae_attn_set_coop(int v) { g_attn_coop = v; return 0; }
 
 extern "C" int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward) {
@@ -1035,13 +1088,15 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
         if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
         if (g_attn_coop || a.has_drop) {
-            if (d.Lq > 32 && d.Lk > 64) {
+            int rc = 0;
+            if (d.Lq > 32 && d.Lk > 64 && g_attn_nq != 1) {
                 dim3 grid((unsigned)cdiv(d.Lq, 256), (unsigned)d.H, (unsigned)d.B);
-                ATTN_DISPATCH3(attn_fwd_coop_kernel, grid, s, a, 2, );
+                ATTN_DISPATCH_COOP(rc, attn_fwd_coop_kernel, grid, s, a, 2, );
             } else {
                 dim3 grid((unsigned)cdiv(d.Lq, 128), (unsigned)d.H, (unsigned)d.B);
-                ATTN_DISPATCH3(attn_fwd_coop_kernel, grid, s, a, 1, );
+                ATTN_DISPATCH_COOP(rc, attn_fwd_coop_kernel, grid, s, a, 1, );
             }
+            if (rc) return rc;
             return hip_launch_status();
         }
         if (d.Lq > 32 && d.Lk > 64) {  // 64 query rows per wave: K / V fragments are fetched once for two query blocks
@@ -1083,8 +1138,10 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
         if (g_attn_coop || a.has_drop) {
-            ATTN_DISPATCH3(attn_bwd_dq_coop_kernel, gq, s, a, );
-            ATTN_DISPATCH3(attn_bwd_dkdv_coop_kernel, gk, s, a, );
+            int rc = 0;
+            ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );
+            ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
+            if (rc) return rc;
         } else {
             ATTN_DISPATCH3(attn_bwd_dq_bf16_kernel, gq, s, a, );
             ATTN_DISPATCH3(attn_bwd_dkdv_bf16_kernel, gk, s, a, );
