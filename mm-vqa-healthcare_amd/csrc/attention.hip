@@ -804,7 +804,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 
 template <bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) {
-    constexpr int BUF = 2 * (RIMG + TILE_LDS);  // Q row, Q tr, dO row, dO tr
+    // Q row, Q tr, dO row, dO tr images + the tile's 32 log-sum-exp and 32 delta values (staged with the tile by
+    // threads 0..15: as per-lane global loads inside the tile they cost 13 % of the kernel -- timing ablation)
+    constexpr int IMG = 2 * (RIMG + TILE_LDS), BUF = IMG + 256;
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -836,21 +838,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     const int nqt = (int)((a.Lq + 31) / 32);
     s16x8 qreg = coop_load(qbase, a.q_sl, 0, a.Lq, t);
     s16x8 doreg = coop_load(dobase, a.o_sl, 0, a.Lq, t);
+    // threads 0..7: lse[4 t .. 4 t + 3], threads 8..15: delta[...] of the tile (rows padded to lse_stride % 32 == 0)
+    const float* ldsrc = (t < 8 ? lrow : drow) + 4 * (t & 7);
+    f32x4 ldreg = t < 16 ? *(const f32x4*)ldsrc : (f32x4){0.f, 0.f, 0.f, 0.f};
     put_row_img(lds, qreg, t);
     put_tr_img(lds + RIMG, qreg, t);
     put_row_img(lds + RIMG + TILE_LDS, doreg, t);
     put_tr_img(lds + 2 * RIMG + TILE_LDS, doreg, t);
+    if (t < 16) *(f32x4*)(lds + IMG + 16 * t) = ldreg;
     if (nqt > 1) {
         qreg = coop_load(qbase, a.q_sl, 32, a.Lq, t);
         doreg = coop_load(dobase, a.o_sl, 32, a.Lq, t);
+        if (t < 16) ldreg = *(const f32x4*)(ldsrc + 32);
     }
     coop_barrier();
     for (int qt = 0; qt < nqt; ++qt) {
         const bool last = qt + 1 == nqt;
         s16x8 qreg2 = qreg, doreg2 = doreg;
+        f32x4 ldreg2 = ldreg;
         if (qt + 2 < nqt) {
             qreg2 = coop_load(qbase, a.q_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
             doreg2 = coop_load(dobase, a.o_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
+            if (t < 16) ldreg2 = *(const f32x4*)(ldsrc + (int64_t)(qt + 2) * 32);
         }
         const char* qimg = lds + (qt & 1) * BUF;
         const char* qtr = qimg + RIMG;
@@ -859,9 +868,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
         if (active) {
             f32x4 lse4[4], dl4[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                lse4[g4] = *(const f32x4*)(lrow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
-                dl4[g4] = *(const f32x4*)(drow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
+            for (int g4 = 0; g4 < 4; ++g4) {  // broadcast LDS reads: rows 8 g4 + 4 h .. + 3 of the tile
+                lse4[g4] = *(const f32x4*)(qimg + IMG + 4 * (8 * g4 + 4 * h));
+                dl4[g4] = *(const f32x4*)(qimg + IMG + 128 + 4 * (8 * g4 + 4 * h));
             }
             s16x8 qfa[4], dofa[4];
 #pragma unroll
@@ -909,8 +918,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
             put_tr_img(nb + RIMG, qreg, t);
             put_row_img(nb + RIMG + TILE_LDS, doreg, t);
             put_tr_img(nb + 2 * RIMG + TILE_LDS, doreg, t);
+            if (t < 16) *(f32x4*)(nb + IMG + 16 * t) = ldreg;
         }
-        qreg = qreg2; doreg = doreg2;
+        qreg = qreg2; doreg = doreg2; ldreg = ldreg2;
         coop_barrier();
     }
     if (active && key_ok) {
