@@ -74,6 +74,8 @@ def fill_deterministic(module_or_sd, salt: int = 0, skip=()):
             continue
         if name.endswith("decoder_pos_embed"):  # fixed sin-cos table (prediction_heads.py:52-55)
             continue
+        if name.endswith("positional_encoding.pe"):  # fixed sinusoid buffer of the decoder head (m3ae_decoder.py:24-33)
+            continue
         mean, std = _std_for(name, t.shape)
         t.copy_(det_normal(name, t.shape, std=std, mean=mean, salt=salt).to(t.dtype))
     return module_or_sd

@@ -494,3 +494,100 @@ def t5_loss(sd, enc_in, labels, heads):
     logits = (dec * d ** -0.5) @ sd["t5.shared.weight"].t()
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100)
     return loss, logits
+
+
+# ------------------------------------------------------------------------------------------------
+# Decoder-only generative head (m3ae/modules/m3ae_decoder.py) -- SURVEY 8f-3.
+# The reference's quirks are part of the contract and are restated as they are:
+#   * `target_embed += positional_encoding(target_embed)` (:127) makes the input 2 * emb + pe;
+#   * every layer is fed `target_embed`, not the previous layer's output (:131-134): only the LAST layer's
+#     output reaches `final_linear`, layers 0..4 are dead compute and their parameters never get a gradient;
+#   * criterion(mean over non-pad golden tokens) * padding_mask, summed / padding_mask.sum() (:366-368) is that
+#     same mean again;
+#   * the [SEP] at the end of every target is replaced by [PAD] in the decoder INPUT (:345-348), and the padding mask
+#     is taken from that input.
+# ------------------------------------------------------------------------------------------------
+def decoder_pe(T, d):
+    """PositionalEncoding (m3ae_decoder.py:24-33)."""
+    pe = torch.zeros(T, d)
+    pos = torch.arange(0, T, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def torch_mha(sd, prefix, xq, xkv, heads, attn_mask=None, key_padding_mask=None):
+    """nn.MultiheadAttention(batch_first=True) forward in eval mode (third party: torch; called at
+    m3ae_decoder.py:61-62,79-80): packed in_proj (q | k | v rows), scores / sqrt(dh), boolean masks -> -inf."""
+    D = xq.shape[-1]
+    W, b = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    q = xq @ W[:D].t() + b[:D]
+    k = xkv @ W[D:2 * D].t() + b[D:2 * D]
+    v = xkv @ W[2 * D:].t() + b[2 * D:]
+    qh, kh, vh = split_heads(q, heads), split_heads(k, heads), split_heads(v, heads)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(D // heads)
+    if attn_mask is not None:
+        s = s.masked_fill(attn_mask[None, None], float("-inf"))
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    o = merge_heads(torch.softmax(s, dim=-1) @ vh)
+    return o @ sd[prefix + ".out_proj.weight"].t() + sd[prefix + ".out_proj.bias"]
+
+
+def decoder_layer(sd, p, t, enc, pad_mask_dec, causal, heads=8):
+    """DecoderLayer.forward (m3ae_decoder.py:55-90), eval mode."""
+    x = t + torch_mha(sd, p + ".mha1", layer_norm(sd, p + ".pre_norm", t, 1e-5), layer_norm(sd, p + ".pre_norm", t, 1e-5),
+                      heads, causal, pad_mask_dec)
+    xn = layer_norm(sd, p + ".layernorm1", x, 1e-5)
+    x = x + torch_mha(sd, p + ".mha2", xn, enc, heads)
+    xn = layer_norm(sd, p + ".layernorm2", x, 1e-5)
+    f = torch.relu(xn @ sd[p + ".ffn.0.weight"].t() + sd[p + ".ffn.0.bias"]) @ sd[p + ".ffn.2.weight"].t() + sd[p + ".ffn.2.bias"]
+    return layer_norm(sd, p + ".layernorm3", x + f, 1e-5)
+
+
+def decoder_forward(sd, target_in, padding_mask, enc, num_layers=6, heads=8, prefix="decoder"):
+    """Decoder.forward (m3ae_decoder.py:118-138).  `padding_mask`: True = real token, or None (generation)."""
+    T = target_in.shape[1]
+    emb = sd[prefix + ".target_embedding.weight"][target_in]
+    t = emb + (emb + decoder_pe(T, emb.shape[-1]))          # `+=` of the positional-encoding OUTPUT (:127)
+    causal = ~torch.tril(torch.ones(T, T, dtype=torch.bool))
+    pad = None if padding_mask is None else ~padding_mask
+    x = None
+    for i in range(num_layers):                              # every layer reads `t` (:131-134)
+        x = decoder_layer(sd, f"{prefix}.dec_layers.{i}", t, enc, pad, causal, heads)
+    return x @ sd[prefix + ".final_linear.weight"].t() + sd[prefix + ".final_linear.bias"]
+
+
+def decoder_inputs(target_tokens, sep_id, pad_id):
+    """m3ae_decoder.py:344-351,362: input = tokens[:, :-1] with [SEP] -> [PAD]; golden = tokens[:, 1:]."""
+    tin = target_tokens[:, :-1].clone()
+    tin[tin == sep_id] = pad_id
+    return tin, tin != pad_id, target_tokens[:, 1:]
+
+
+def decoder_loss(sd, target_tokens, enc, sep_id=102, pad_id=0, **kw):
+    tin, mask, gold = decoder_inputs(target_tokens, sep_id, pad_id)
+    logits = decoder_forward(sd, tin, mask, enc, **kw)
+    ce = F.cross_entropy(logits.transpose(1, 2), gold, ignore_index=pad_id)   # criterion (:226, :366)
+    loss = (ce * mask).sum() / mask.sum()                                     # (:366-367)
+    return loss, logits
+
+
+def decoder_search(sd, enc, cls_id=101, sep_id=102, eos_id=None, pad_id=0, max_len=128, **kw):
+    """Decoder.search_path (m3ae_decoder.py:141-182): greedy, the whole prefix is re-run every step (no cache)."""
+    B = enc.shape[0]
+    seq = torch.full((B, 1), cls_id, dtype=torch.long)
+    finished = torch.zeros(B, dtype=torch.bool)
+    for _ in range(max_len):
+        nxt = decoder_forward(sd, seq, None, enc, **kw)[:, -1].argmax(-1)
+        finished |= (nxt == sep_id) | ((nxt == eos_id) if eos_id is not None else torch.zeros(B, dtype=torch.bool))
+        seq = torch.cat([seq, nxt[:, None]], dim=1)
+        if finished.all():
+            break
+    seq = seq[:, 1:]
+    for i in range(B):
+        hit = torch.where((seq[i] == sep_id) | ((seq[i] == eos_id) if eos_id is not None else torch.zeros_like(seq[i], dtype=torch.bool)))[0]
+        if len(hit) > 0:
+            seq[i, hit[0] + 1:] = pad_id
+    return F.pad(seq, (0, max_len - seq.shape[1]), value=pad_id)

@@ -278,8 +278,85 @@ def run_t5():
     print("[t5] loss", loss.item(), "trainable", len(res["trainable_names"]), "with grad", len(names))
 
 
+DEC_M3AE = dict(image_size=64, hidden_size=768, num_heads=12, num_top_layer=1, input_image_embed_size=128,
+                input_text_embed_size=128, vocab_size=1000)  # hidden 768: m3ae_decoder.py:311 views CLS as [B, 2, 768]
+DEC_ARCH = dict(vision_layers=2, vision_width=128, text_layers=1, text_hidden=128, text_heads=2, text_inter=512,
+                vocab=1000)
+
+
+def run_decoder():
+    """the reference's DecoderModel (m3ae_decoder.py) on a small frozen M3AE (fusion width 768 is
+    hard-wired), its own 6 x (d 768, 8 heads, d_ff 3072) decoder, a stub tokenizer (vocabulary 1200, BERT special ids),
+    eval mode.  Stores logits, loss, per-parameter gradient norms (and which parameters get none), greedy tokens."""
+    rs.install()
+    import types
+    import m3ae.modules.m3ae_decoder as dm
+    import m3ae.modules.m3ae_t5_utils as tu
+
+    VOC = 1200
+
+    class Tok:
+        vocab_size, cls_token_id, sep_token_id, pad_token_id, eos_token_id = VOC, 101, 102, 0, None
+
+        @staticmethod
+        def from_pretrained(*a, **k):
+            return Tok()
+
+        def __call__(self, texts, **k):
+            rows = [[101] + [int(t) for t in s.split()] + [102] for s in texts]
+            T = max(len(r) for r in rows)
+            return types.SimpleNamespace(input_ids=torch.tensor([r + [0] * (T - len(r)) for r in rows]))
+
+        def decode(self, seq, **k):
+            return " ".join(str(int(t)) for t in seq)
+
+    dm.BertTokenizer = Tok
+    tu.set_metrics = lambda m: None
+    cfg = rs.reference_config(**DEC_M3AE)
+    cfg.update(decoder_load_path="", mm_encoder_inputs_include_cls_feats=True,
+               mm_encoder_inputs_include_imagetext_feats=False)
+    torch.manual_seed(0)
+    rs.build_reference_model(cfg, **DEC_ARCH)  # patches the network loaders used by M3AETransformerSS.__init__
+    m = dm.DecoderModel(cfg)
+    synth.fill_deterministic(m)
+    m.eval()
+    for n in ("train", "val", "test"):
+        for k in ("loss", "rouge1", "rouge2", "bleu_score", "exact_match"):
+            setattr(m, f"{n}_vqa_{k}", lambda *a, **kw: torch.tensor(0.0))
+    rs.chdir_ref()
+    batch = synth.synthetic_batch(2, text_len=32, image_size=64, vocab_size=1000, rank=0)
+    lab = synth.det_randint("dec_labels", 103, VOC, (2, 4), salt=9)
+    batch["vqa_answer"] = [[" ".join(str(int(t)) for t in lab[0])], [" ".join(str(int(t)) for t in lab[1, :2])]]
+    out = m.training_step(batch, 0)
+    loss = out["loss"]
+    loss.backward()
+    tokens = Tok()([a[0] for a in batch["vqa_answer"]]).input_ids
+    with torch.no_grad():
+        cls = m.m3ae.infer(batch)["multi_modal_cls_feats"].view(-1, 2, 768)
+        tin = tokens[:, :-1].clone()
+        tin[tin == 102] = 0
+        logits, _ = m.decoder(tin, tin != 0, cls)
+        m.decoder.max_len = 16
+        greedy = m.decoder.search_path(cls, Tok())
+    res = {"loss": np.float64(loss.item()), "logits": logits.numpy(), "tokens": tokens.numpy(), "cls": cls.numpy(),
+           "greedy": greedy.numpy()}
+    names, gn = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    res["grad_names"], res["grad_norm"] = np.array(names), np.array(gn)
+    res["trainable_nograd"] = np.array([n for n, p in m.named_parameters() if p.requires_grad and p.grad is None])
+    res["state_names"] = np.array(list(m.state_dict().keys()))
+    res["state_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+    np.savez_compressed(os.path.join(GOLD, "tiny_decoder.npz"), **res)
+    print("[decoder] loss", loss.item(), "with grad", len(names), "trainable without grad", len(res["trainable_nograd"]),
+          "greedy", greedy[:, :6].tolist())
+
+
+
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -287,6 +364,8 @@ def main():
         run_pretrain()
     if "t5" in what:
         run_t5()
+    if "decoder" in what:
+        run_decoder()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
 

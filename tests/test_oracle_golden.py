@@ -128,3 +128,42 @@ def test_tiny_t5_head_matches_reference():
     for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
         mine = sd[n].grad.double().norm().item()
         assert abs(mine - r) <= 1e-3 * r + 1e-9, (n, mine, r)
+
+
+def _decoder_sd():
+    """Deterministic decoder-head weights by reference state_dict name (the fixture stores names + shapes, no values)."""
+    from m3ae_amd import synth
+    g = load_golden("tiny_decoder.npz")
+    sd = {}
+    for n, shp in zip(g["state_names"].tolist(), g["state_shapes"].tolist()):
+        if n.startswith("decoder."):
+            sd[n] = torch.empty(eval(shp), dtype=torch.float32)
+    synth.fill_deterministic(sd)
+    sd["decoder.positional_encoding.pe"] = O.decoder_pe(1024, 768).unsqueeze(0)
+    return sd, g
+
+
+def test_tiny_decoder_head_matches_reference():
+    """the decoder-only generative head (m3ae_decoder.py) incl. its quirks -- doubled embedding, every
+    layer fed the embedding, only the last layer trained -- against the reference's DecoderModel."""
+    sd, g = _decoder_sd()
+    for t in sd.values():
+        t.requires_grad_(True)
+    enc = torch.from_numpy(g["cls"])
+    tokens = torch.from_numpy(g["tokens"])
+    loss, logits = O.decoder_loss(sd, tokens, enc)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=2e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    names = [n for n in g["grad_names"].tolist() if n.startswith("decoder.")]
+    assert len(names) == 23
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = sd[n].grad.double().norm().item()
+        assert abs(mine - r) <= 1e-3 * r + 1e-9, (n, mine, r)
+    # layers 0..4 are dead compute in the reference: no gradient reaches them
+    dead = [n for n in g["trainable_nograd"].tolist()]
+    assert len(dead) == 100 and all(n.startswith("decoder.dec_layers.") and int(n.split(".")[2]) < 5 for n in dead)
+    assert all(sd[n].grad is None or float(sd[n].grad.abs().max()) == 0.0 for n in dead)
+    with torch.no_grad():
+        greedy = O.decoder_search({k: v.detach() for k, v in sd.items()}, enc, max_len=16)
+    np.testing.assert_array_equal(greedy.numpy(), g["greedy"])
