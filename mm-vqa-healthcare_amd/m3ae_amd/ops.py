@@ -491,12 +491,12 @@ class SelfAttnFn(torch.autograd.Function):
     """softmax(QK^T / sqrt(dh) + mask) V on a packed [B, L, 3D] projection (rows Q | K | V)."""
 
     @staticmethod
-    def forward(ctx, qkv, key_mask, heads, dropout=None):
+    def forward(ctx, qkv, key_mask, heads, dropout=None, causal=False):
         D = qkv.shape[-1] // 3
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-        o, lse = attn_forward(q, k, v, heads, key_mask, dropout=dropout)
+        o, lse = attn_forward(q, k, v, heads, key_mask, dropout=dropout, causal=causal)
         ctx.save_for_backward(qkv, o, lse, key_mask)
-        ctx.heads, ctx.dropout = heads, dropout
+        ctx.heads, ctx.dropout, ctx.causal = heads, dropout, causal
         return o
 
     @staticmethod
@@ -505,8 +505,8 @@ class SelfAttnFn(torch.autograd.Function):
         D = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
         attn_backward(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, do.contiguous(), dqkv[..., :D],
-                      dqkv[..., D:2 * D], dqkv[..., 2 * D:], ctx.heads, key_mask, dropout=ctx.dropout)
-        return dqkv, None, None, None
+                      dqkv[..., D:2 * D], dqkv[..., 2 * D:], ctx.heads, key_mask, dropout=ctx.dropout, causal=ctx.causal)
+        return dqkv, None, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):
@@ -524,16 +524,17 @@ class CrossAttnFn(torch.autograd.Function):
     def backward(ctx, do):
         q, kv, o, lse, key_mask = ctx.saved_tensors
         D = q.shape[-1]
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        # same strides as the (possibly sliced) inputs: the kernels address dq / dk / dv with the q / k / v strides
+        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device)
+        dkv = torch.empty_strided(kv.shape, kv.stride(), dtype=kv.dtype, device=kv.device)
         attn_backward(q, kv[..., :D], kv[..., D:], o, lse, do.contiguous(), dq, dkv[..., :D], dkv[..., D:], ctx.heads,
                       key_mask, dropout=ctx.dropout)
         return dq, dkv, None, None, None
 
 
-def self_attention(qkv, key_mask, heads, dropout=None):
+def self_attention(qkv, key_mask, heads, dropout=None, causal=False):
     """dropout = (p, seed): attention-probability dropout (mask rows (b*H + h)*Lq + q, columns k)."""
-    return SelfAttnFn.apply(qkv, key_mask, heads, dropout)
+    return SelfAttnFn.apply(qkv, key_mask, heads, dropout, causal)
 
 
 def cross_attention(q, kv, key_mask, heads, dropout=None):

@@ -82,6 +82,16 @@ class SyntheticDataModule:
             lab = synth.det_randint("t5_labels", 2, 32128, (self.B, 6), salt=31 + self.rank + self.world * idx)
             lab[:, -1] = 1
             b["t5_labels"] = lab.to(self.device)
+        if self.head == "decoder":  # [CLS] answer tokens [SEP] [PAD]... with BERT's special ids (m3ae_decoder.py:336-342)
+            import torch
+            T = 6
+            ids = synth.det_randint("dec_tokens", 1000, 30522, (self.B, T), salt=37 + self.rank + self.world * idx)
+            n = synth.det_randint("dec_len", 1, T - 1, (self.B,), salt=38 + self.rank + self.world * idx)
+            pos = torch.arange(T).view(1, T)
+            ids = torch.where(pos == 0, torch.full_like(ids, 101), ids)
+            ids = torch.where(pos == (n.view(-1, 1) + 1), torch.full_like(ids, 102), ids)
+            ids = torch.where(pos > (n.view(-1, 1) + 1), torch.zeros_like(ids), ids)
+            b["decoder_tokens"] = ids.to(self.device)
         return b
 
     def train_batches(self, epoch):
@@ -240,15 +250,17 @@ def init_distributed():
 
 
 def build_model(cfg, head, device):
-    from .modules import M3AETransformerSS, T5VQA_MMEncoderInput
+    from .modules import DecoderModel, M3AETransformerSS, T5VQA_MMEncoderInput
     if head == "t5":
         model = T5VQA_MMEncoderInput(cfg)
         model.unfreeze_top_layers(cfg["unfreeze_num_encoder_layers"], cfg["unfreeze_num_decoder_layers"])
+    elif head == "decoder":
+        model = DecoderModel(cfg)
     else:
         model = M3AETransformerSS(cfg)
     lp = cfg["load_path"]
     if lp and os.path.exists(lp):
-        target = model.m3ae if head == "t5" else model
+        target = model.m3ae if head in ("t5", "decoder") else model
         target._load(lp)  # m3ae_module.py:104-113: ckpt["state_dict"], strict=False, pos-embed resize
     else:
         # no checkpoint on disk (offline box): deterministic random init of the named architecture
