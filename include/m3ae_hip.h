@@ -159,6 +159,11 @@ int m3ae_roberta_embed_bwd(const int64_t* ids, const void* d_out, float* d_word,
  * row-major flattening of conv1.weight[width, 3, P, P]) and [cls | patches] + positional_embedding.
  */
 int m3ae_patchify(const float* img, void* out, int64_t B, int64_t R, int64_t P, int dtype, void* stream);
+/* Input pipeline tail (transforms/transform.py:60-67 ToTensor + Normalize, after the host-side PIL resize / centre crop):
+ * uint8 [B, H, W, 3] (RGB, as uploaded from pinned host memory: a quarter of the fp32 PCIe bytes) ->
+ * fp32 [B, 3, H, W] with out = (u / 255 - mean[c]) / std[c], the same two IEEE divisions torch performs. */
+int m3ae_image_normalize_u8(const uint8_t* in, float* out, int64_t B, int64_t H, int64_t W, const float* mean3,
+                            const float* std3, void* stream);
 int m3ae_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* out, int64_t B, int64_t G,
                         int64_t D, int dtype, void* stream);
 int m3ae_vit_tokens_bwd(const void* d_out, void* d_patch, float* d_cls, float* d_pos, int64_t B, int64_t G,

@@ -130,6 +130,17 @@ __global__ void patchify_kernel(const float* img, T* out, int64_t B, int64_t R, 
         Elem<T>::st(out + i, img[((b * 3 + c) * R + gy * P + py) * R + gx * P + px]);
     }
 }
+// NHWC uint8 -> NCHW fp32, (u / 255 - mean) / std: one thread per output pixel-channel, reads coalesced over x
+__global__ void image_normalize_u8_kernel(const uint8_t* in, float* out, int64_t B, int64_t H, int64_t W, float m0,
+                                          float m1, float m2, float s0, float s1, float s2) {
+    const int64_t total = B * 3 * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = i % W, y = (i / W) % H, c = (i / (W * H)) % 3, b = i / (3 * W * H);
+        const float u = (float)in[((b * H + y) * W + x) * 3 + c];
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        out[i] = (u / 255.0f - mean) / sd;
+    }
+}
 // out[b][0] = cls + pos[0];  out[b][1 + i] = patch[b][i] + pos[1 + i]
 template <typename T>
 __global__ void vit_tokens_fwd_kernel(const T* patch, const float* cls, const float* pos, T* out, int64_t B, int64_t G,
@@ -391,6 +402,14 @@ extern "C" int m3ae_patchify(const float* img, void* out, int64_t B, int64_t R, 
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = B * (R / P) * (R / P) * 3 * P * P;
     DT_SWITCH(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, img, (T*)out, B, R, P));
+    return hip_launch_status();
+}
+extern "C" int m3ae_image_normalize_u8(const uint8_t* in, float* out, int64_t B, int64_t H, int64_t W,
+                                       const float* mean3, const float* std3, void* stream) {
+    if (!in || !out || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0) return M3AE_ERR_ARG;  // mean3 / std3: HOST arrays
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(image_normalize_u8_kernel, dim3(ew_grid(B * 3 * H * W)), dim3(EW_BLOCK), 0, s, in, out, B, H, W,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     return hip_launch_status();
 }
 extern "C" int m3ae_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* out, int64_t B,

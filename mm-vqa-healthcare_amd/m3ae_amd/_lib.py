@@ -54,6 +54,7 @@ _SIGS = {
     "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_patchify": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, vp]),
+    "m3ae_image_normalize_u8": (C.c_int, [vp, vp, i64, i64, i64, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     "m3ae_vit_tokens_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_vit_tokens_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_bce_logits": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, C.c_int, vp]),

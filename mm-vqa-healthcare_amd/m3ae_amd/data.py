@@ -1,0 +1,244 @@
+"""Input pipeline for the hot path: arrow reader + CLIP transform + collate + tokenisation, producing
+the batch dict of the drop-in boundary (8b) with the NEXT batch decoded, resized and uploaded while the current one
+trains.
+
+Reference pieces restated (host side, Python like the reference's):
+  * `BaseDataset` (m3ae/datasets/base_dataset.py:12-228): `{data_dir}/{name}.arrow` written by prepro/make_arrow.py
+    (:126-204: columns image, questions, answers, answer_labels, answer_scores, image_id, question_id, answer_type,
+    split), one sample per (image row, question index) (`index_mapper`, :72-81);
+  * `VQAVQARADDataset.__getitem__` (vqa_vqa_rad_dataset.py:24-43);
+  * `clip_transform` (transforms/transform.py:60-67): PIL RGBA -> `Resize(size, BICUBIC)` (shorter side, torchvision's
+    integer rounding) -> `CenterCrop(size)` -> RGB -> ToTensor -> Normalize(CLIP mean / std);
+  * `collate` (base_dataset.py:165-228) for the fine-tuning keys (`*_mlm` fields only for pre-training: not built).
+
+MI355X side: decode + bicubic resize stay on host cores (PIL releases the GIL; a thread pool of `num_workers`), the
+crop is handed over as uint8 NHWC in PINNED memory (a quarter of the fp32 bytes over PCIe), copied on a side HIP
+stream, and ToTensor + Normalize run in one kernel on the GPU (`m3ae_image_normalize_u8`, same IEEE arithmetic as
+torch: bit-equal to the reference's tensor).  `ArrowDataModule.train_batches` keeps `prefetch` batches in flight.
+"""
+import ctypes as C
+import io
+import os
+import queue
+import random
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import CLIP_MEAN, CLIP_STD
+
+
+# ------------------------------------------------------------------------------------------------------------
+# transform (host part)
+# ------------------------------------------------------------------------------------------------------------
+def clip_resize_crop(img, size):
+    """PIL image -> uint8 [size, size, 3]: transform.py:60-64 (Resize BICUBIC on the RGBA image, CenterCrop, RGB)."""
+    from PIL import Image
+    img = img.convert("RGBA")                      # base_dataset.py:92-93
+    w, h = img.size
+    if w <= h:                                     # torchvision Resize(int): shorter side -> size, long side truncated
+        nw, nh = size, int(size * h / w)
+    else:
+        nw, nh = int(size * w / h), size
+    if (nw, nh) != (w, h):
+        img = img.resize((nw, nh), Image.BICUBIC)
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    img = img.crop((left, top, left + size, top + size)).convert("RGB")
+    return np.asarray(img, dtype=np.uint8)
+
+
+def normalize_on_device(u8_nhwc, stream=None):
+    """uint8 [B, H, W, 3] (device) -> fp32 [B, 3, H, W]: ToTensor + Normalize in one kernel."""
+    B, H, W, _ = u8_nhwc.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=u8_nhwc.device)
+    mean = (C.c_float * 3)(*CLIP_MEAN)
+    std = (C.c_float * 3)(*CLIP_STD)
+    s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    _lib.check(_lib.lib().m3ae_image_normalize_u8(C.c_void_p(u8_nhwc.data_ptr()), C.c_void_p(out.data_ptr()), B, H, W,
+                                                  mean, std, s), "m3ae_image_normalize_u8")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# tokenizer
+# ------------------------------------------------------------------------------------------------------------
+def load_tokenizer(cfg):
+    """base_datamodule.py:13-26: `RobertaTokenizerFast.from_pretrained(path, local_files_only=True)`."""
+    name = cfg["tokenizer"]
+    from transformers import BertTokenizerFast, RobertaTokenizerFast
+    if "roberta" in name:
+        return RobertaTokenizerFast.from_pretrained(name, local_files_only=True)
+    return BertTokenizerFast.from_pretrained(name, do_lower_case="uncased" in name, local_files_only=True)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# dataset
+# ------------------------------------------------------------------------------------------------------------
+class ArrowVQADataset:
+    """BaseDataset + VQAVQARADDataset for `{data_dir}/vqa_vqa_rad_{split}.arrow` (or any `names`)."""
+
+    def __init__(self, data_dir, split, image_size, max_text_len, tokenizer, names=None):
+        import pyarrow as pa
+        self.names = names or [f"vqa_vqa_rad_{split}"]
+        tables = []
+        for name in self.names:
+            path = os.path.join(data_dir, f"{name}.arrow")
+            if os.path.isfile(path):
+                tables.append(pa.ipc.RecordBatchFileReader(pa.memory_map(path, "r")).read_all())
+        if not tables:
+            raise FileNotFoundError(f"no arrow table for {self.names} under {data_dir!r}")
+        self.table = pa.concat_tables(tables)
+        self.image_size, self.max_text_len, self.tokenizer = image_size, max_text_len, tokenizer
+        self.all_texts = self.table["questions"].to_pylist()
+        self.index_mapper = [(i, j) for i, texts in enumerate(self.all_texts) for j in range(len(texts))]
+
+    def __len__(self):
+        return len(self.index_mapper)
+
+    def image_u8(self, row):
+        from PIL import Image
+        return clip_resize_crop(Image.open(io.BytesIO(self.table["image"][row].as_py())), self.image_size)
+
+    def __getitem__(self, index):
+        row, qi = self.index_mapper[index]
+        text = self.all_texts[row][qi]
+        enc = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_text_len)
+        t = self.table
+        return {
+            "image_u8": self.image_u8(row),
+            "text": text,
+            "input_ids": list(enc["input_ids"]),
+            "attention_mask": list(enc["attention_mask"]),
+            "vqa_answer": t["answers"][row][qi].as_py(),
+            "vqa_labels": t["answer_labels"][row][qi].as_py(),
+            "vqa_scores": t["answer_scores"][row][qi].as_py(),
+            "answer_types": t["answer_type"][row][qi].as_py(),
+            "qid": t["question_id"][row][qi].as_py(),
+        }
+
+
+def collate_host(samples, pin=True):
+    """base_dataset.py:165-228 (fine-tuning keys): images stacked as uint8 NHWC, ids / masks as int64 tensors."""
+    B = len(samples)
+    S = max(len(s["input_ids"]) for s in samples)
+    img = torch.from_numpy(np.stack([s["image_u8"] for s in samples]))
+    ids = torch.zeros((B, S), dtype=torch.long)
+    mask = torch.zeros((B, S), dtype=torch.long)
+    for i, s in enumerate(samples):
+        ids[i, : len(s["input_ids"])] = torch.tensor(s["input_ids"])
+        mask[i, : len(s["attention_mask"])] = torch.tensor(s["attention_mask"])
+    if pin and torch.cuda.is_available():
+        img, ids, mask = img.pin_memory(), ids.pin_memory(), mask.pin_memory()
+    return {"image_u8": img, "text_ids": ids, "text_masks": mask,
+            "text": [s["text"] for s in samples],
+            "vqa_answer": [s["vqa_answer"] for s in samples], "vqa_labels": [s["vqa_labels"] for s in samples],
+            "vqa_scores": [s["vqa_scores"] for s in samples], "answer_types": [s["answer_types"] for s in samples],
+            "qid": [s["qid"] for s in samples]}
+
+
+def to_device_batch(hb, device, copy_stream=None):
+    """Upload a host batch (pinned) and finish the transform on the GPU -> the 8b batch dict."""
+    cur = torch.cuda.current_stream()
+    cs = copy_stream or cur
+    with torch.cuda.stream(cs):
+        u8 = hb["image_u8"].to(device, non_blocking=True)
+        ids = hb["text_ids"].to(device, non_blocking=True)
+        mask = hb["text_masks"].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cs)
+    out = {k: v for k, v in hb.items() if k not in ("image_u8", "text_ids", "text_masks")}
+    out.update(_u8=u8, text_ids=ids, text_masks=mask, text_labels=None, _ready=ev)
+    return out
+
+
+def finish_batch(db):
+    """Called on the compute stream right before the step: wait for the upload, normalise, build labels."""
+    torch.cuda.current_stream().wait_event(db.pop("_ready"))
+    u8 = db.pop("_u8")
+    db["image"] = [normalize_on_device(u8)]
+    db["text_labels"] = torch.full_like(db["text_ids"], -100)
+    for t in (u8, db["text_ids"], db["text_masks"]):
+        t.record_stream(torch.cuda.current_stream())
+    return db
+
+
+# ------------------------------------------------------------------------------------------------------------
+# datamodule
+# ------------------------------------------------------------------------------------------------------------
+class ArrowDataModule:
+    """MTDataModule / BaseDataModule for the hot path: DistributedSampler-style sharding (seeded shuffle per epoch,
+    multitask_datamodule.py:44-48), `per_gpu_batchsize` batches, background decode + upload."""
+
+    def __init__(self, cfg, rank=0, world=1, device="cuda", tokenizer=None, prefetch=3, head="cls"):
+        self.cfg, self.rank, self.world, self.device, self.head = cfg, rank, world, device, head
+        self.B = cfg["per_gpu_batchsize"]
+        self.tokenizer = tokenizer or load_tokenizer(cfg)
+        root = cfg["data_root"]
+        mk = lambda split: ArrowVQADataset(root, split, cfg["image_size"], cfg["max_text_len"], self.tokenizer)
+        self.train_set = mk("train")
+        self.val_set = self._try(mk, "val") or self.train_set
+        self.test_set = self._try(mk, "test") or self.val_set
+        self.train_samples, self.val_samples = len(self.train_set), len(self.val_set)
+        self.workers = max(int(cfg.get("num_workers", 8)), 1)
+        self.prefetch = prefetch
+        self.copy_stream = torch.cuda.Stream(device=device) if torch.cuda.is_available() else None
+
+    @staticmethod
+    def _try(mk, split):
+        try:
+            return mk(split)
+        except FileNotFoundError:
+            return None
+
+    def _indices(self, ds, epoch, shuffle):
+        idx = list(range(len(ds)))
+        if shuffle:
+            random.Random(self.cfg["seed"] * 1000 + epoch).shuffle(idx)
+        total = (len(idx) + self.world - 1) // self.world * self.world  # DistributedSampler pads by wrapping around
+        idx += idx[: total - len(idx)]
+        return idx[self.rank::self.world]
+
+    def _stream(self, ds, idx, drop_last):
+        """Generator of device batches; host decode runs `prefetch` batches ahead in a thread pool."""
+        chunks = [idx[i:i + self.B] for i in range(0, len(idx), self.B)]
+        if drop_last:
+            chunks = [c for c in chunks if len(c) == self.B]
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def producer():
+            with ThreadPoolExecutor(self.workers) as pool:
+                for c in chunks:
+                    if stop.is_set():
+                        break
+                    q.put(collate_host(list(pool.map(ds.__getitem__, c))))
+            q.put(None)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        pending = None
+        try:
+            while True:
+                hb = q.get()
+                nxt = None if hb is None else to_device_batch(hb, self.device, self.copy_stream)
+                if pending is not None:
+                    yield finish_batch(pending)   # its upload was issued one batch ago
+                if nxt is None:
+                    break
+                pending = nxt
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+    def train_batches(self, epoch):
+        return self._stream(self.train_set, self._indices(self.train_set, epoch, True), drop_last=False)
+
+    def val_batches(self):
+        return self._stream(self.val_set, self._indices(self.val_set, 0, False), drop_last=False)

@@ -19,8 +19,10 @@ arithmetic around `training_step`:
 * one process per GPU: launched under `python -m torch.distributed.run --nproc-per-node N main.py with ...`
   (RANK / LOCAL_RANK / WORLD_SIZE), RCCL through `torch.distributed`; `num_gpus` * `num_nodes` must equal the world.
 
-Data: the arrow input pipeline is the next row (8f-2); until then `data_root=synthetic` (or an empty `data_root`)
-selects `SyntheticDataModule`, which serves batches with the reference's collate schema (base_dataset.py:165-228).
+Data: `data_root=<dir with vqa_vqa_rad_{train,val,test}.arrow>` runs the arrow input pipeline (m3ae_amd/data.py, SURVEY
+8f-2: host decode + bicubic resize in a thread pool, pinned uint8 upload on a side stream, ToTensor + Normalize on
+the GPU); `data_root=synthetic` (or empty) selects `SyntheticDataModule`, which serves deterministic batches with the
+same collate schema (base_dataset.py:165-228).
 """
 import json
 import math
@@ -270,8 +272,9 @@ def build_model(cfg, head, device):
     return model
 
 
-def run(argv, head="cls"):
-    """Entry point shared by main.py / main_t5_m3ae.py: `python main.py with k=v ... named_config ...`."""
+def run(argv, head="cls", tokenizer=None):
+    """Entry point shared by main.py / main_t5_m3ae.py / main_decoder_m3ae.py: `python main.py with k=v ...
+    named_config ...`.  `tokenizer`: optional callable for the arrow pipeline (default: the `tokenizer=` directory)."""
     cfg = config_mod.parse_cli(argv)
     rank, world, dev = init_distributed()
     expect = (cfg["num_gpus"] if isinstance(cfg["num_gpus"], int) else len(cfg["num_gpus"])) * cfg["num_nodes"]
@@ -282,11 +285,15 @@ def run(argv, head="cls"):
         raise SystemExit("per_gpu_batchsize must be set (run_scripts/*.sh pass it explicitly)")
     torch.manual_seed(cfg["seed"])  # pl.seed_everything (main.py:19)
     root = cfg["data_root"]
-    if root not in ("", "synthetic"):
-        raise SystemExit(f"data_root={root!r}: the arrow input pipeline (SURVEY 8f-2) is not built yet; pass "
-                         "data_root=synthetic")
     model = build_model(cfg, head, dev)
-    dm = SyntheticDataModule(cfg, rank, world, dev, head=head)
+    if root in ("", "synthetic"):
+        dm = SyntheticDataModule(cfg, rank, world, dev, head=head)
+    else:
+        from .data import ArrowDataModule  # arrow reader + CLIP transform + collate, prefetched
+        if head != "cls" and getattr(model, "tokenizer", None) is None:
+            raise SystemExit("the generator heads need their answer tokenizer (T5 / BERT vocabulary files) for real data: "
+                             "construct the model with `tokenizer=` or use data_root=synthetic")
+        dm = ArrowDataModule(cfg, rank, world, dev, tokenizer=tokenizer, head=head)
     tr = Trainer(cfg, model, dm, rank, world, dev)
     if cfg.get("resume_from"):
         tr.resume(cfg["resume_from"])

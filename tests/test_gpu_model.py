@@ -353,3 +353,45 @@ def test_trainer_shim_decoder_head_entry_point(tmp_path):
     assert out["global_step"] == 4
     losses = [h[1] for h in out["history"]]
     assert np.isfinite(losses).all() and losses[0] > 5.0  # ~ln(30522) at the start
+
+
+def test_input_pipeline_device_tail_and_trainer_on_arrow_data(tmp_path):
+    """uint8 NHWC upload + ToTensor / Normalize on the GPU is bit-equal to the reference's torch
+    arithmetic; the prefetching datamodule feeds the trainer shim end to end from an arrow file."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from arrow_util import HashTokenizer, write_split
+    from m3ae_amd import data, trainer
+    u8 = torch.randint(0, 256, (3, 40, 56, 3), dtype=torch.uint8, device="cuda")
+    out = data.normalize_on_device(u8)
+    mean = torch.tensor(synth.CLIP_MEAN, device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor(synth.CLIP_STD, device="cuda").view(1, 3, 1, 1)
+    # ToTensor + Normalize (transform.py:65-66) as the reference runs them: on the CPU (IEEE divisions; torch's GPU
+    # `div(scalar)` multiplies by the reciprocal instead and differs in the last bit)
+    ref = (u8.cpu().permute(0, 3, 1, 2).float().div(255) - mean.cpu()) / std.cpu()
+    assert torch.equal(out.cpu(), ref)
+    root = str(tmp_path / "arrows")
+    n_train = write_split(root, "train", 12)
+    write_split(root, "val", 4, seed=100)
+    tok = HashTokenizer()
+    cfg = tiny_config(compute_dtype="bf16", data_root=root, per_gpu_batchsize=4, num_workers=3, seed=1)
+    dm = data.ArrowDataModule(cfg, 0, 1, torch.device("cuda", 0), tokenizer=tok)
+    assert dm.train_samples == n_train
+    batches = list(dm.train_batches(0))
+    assert sum(b["text_ids"].shape[0] for b in batches) == n_train and len(batches) == (n_train + 3) // 4
+    b0 = batches[0]
+    assert b0["image"][0].shape == (4, 3, 64, 64) and b0["image"][0].dtype == torch.float32
+    assert b0["text_labels"].eq(-100).all() and b0["text_ids"].is_cuda
+    # same sample through the dataset directly == through the prefetching loader (order of epoch 0 is seeded)
+    order = dm._indices(dm.train_set, 0, True)
+    s = dm.train_set[order[0]]
+    want = (torch.from_numpy(s["image_u8"]).permute(2, 0, 1).float().div(255) - mean[0].cpu()) / std[0].cpu()
+    assert torch.equal(b0["image"][0][0].cpu(), want) and b0["text_ids"][0].tolist() == s["input_ids"]
+    tiny = ("image_size=64 hidden_size=128 num_heads=2 num_top_layer=2 input_image_embed_size=128 "
+            "input_text_embed_size=128 vocab_size=1000 vit_width=128 vit_layers=3 text_hidden=128 text_layers=2 "
+            "text_heads=2 text_inter=512").split()
+    argv = (["with", f"data_root={root}", "num_gpus=1", "num_nodes=1", "task_finetune_vqa_vqa_rad", "clip16",
+             "text_roberta", "per_gpu_batchsize=4", "batch_size=8", "max_steps=3", "num_workers=2",
+             f"log_dir={tmp_path}", "seed=2"] + tiny)
+    out = trainer.run(argv, tokenizer=tok)
+    assert out["global_step"] == 3 and np.isfinite(out["test"])

@@ -108,3 +108,34 @@ def test_trainer_plan_follows_reference_main():
     targets = torch.tensor([[0.0, 0.6, 1.0], [0.0, 1.0, 0.0]])
     s, n = trainer.vqa_score(logits, targets)
     assert n == 2 and abs(s.item() - 0.6) < 1e-6
+
+
+def test_arrow_dataset_transform_and_collate(tmp_path):
+    """SURVEY 8f-2 host side: arrow reader (make_arrow.py schema), torchvision-style Resize(BICUBIC) + CenterCrop on
+    RGBA -> RGB (transform.py:60-64), per-question index mapping, collate schema (base_dataset.py:165-228)."""
+    from arrow_util import HashTokenizer, write_split
+    from m3ae_amd import data
+    nq = write_split(str(tmp_path), "train", 9)
+    ds = data.ArrowVQADataset(str(tmp_path), "train", 64, 32, HashTokenizer())
+    assert len(ds) == nq == sum(1 + i % 3 for i in range(9))
+    s0 = ds[0]                                    # image 0: 500 x 400, left half red / right half blue
+    assert s0["image_u8"].shape == (64, 64, 3) and s0["image_u8"].dtype == np.uint8
+    assert tuple(s0["image_u8"][32, 28]) == (255, 0, 0) and tuple(s0["image_u8"][32, 36]) == (0, 0, 255)  # split stays centred
+    # Resize(64) of 500 x 400 is 80 x 64 (int(64 * 500 / 400)); the centre crop removes 8 columns on each side
+    from PIL import Image
+    import io
+    ref = Image.open(io.BytesIO(ds.table["image"][0].as_py())).convert("RGBA").resize((80, 64), Image.BICUBIC)
+    np.testing.assert_array_equal(np.asarray(ref.convert("RGB"))[:, 8:72], s0["image_u8"])
+    i_const = next(i for i, (r, q) in enumerate(ds.index_mapper) if r == 2)
+    assert (ds[i_const]["image_u8"] == np.array([10, 128, 250], dtype=np.uint8)).all()  # 200 x 640 portrait, constant colour
+    i_gray = next(i for i, (r, q) in enumerate(ds.index_mapper) if r == 1)
+    g = ds[i_gray]["image_u8"]
+    assert (g[..., 0] == g[..., 1]).all() and (g[..., 1] == g[..., 2]).all()  # "L" -> RGBA -> RGB replicates the channel
+    row, qi = ds.index_mapper[4]
+    assert ds[4]["qid"] == ds.table["question_id"][row][qi].as_py() and ds[4]["text"] == ds.all_texts[row][qi]
+    hb = data.collate_host([ds[i] for i in range(5)], pin=False)
+    assert hb["image_u8"].shape == (5, 64, 64, 3) and hb["image_u8"].dtype == torch.uint8
+    assert hb["text_ids"].shape == (5, 32) and hb["text_ids"].dtype == torch.long
+    assert (hb["text_ids"][:, 0] == 0).all() and ((hb["text_ids"] == 1) == (hb["text_masks"] == 0)).all()
+    assert hb["vqa_labels"][0] == [0] and hb["vqa_scores"][0] == [1.0] and hb["answer_types"][0] in (0, 1)
+    assert isinstance(hb["vqa_answer"][0], list) and isinstance(hb["text"][0], str)
