@@ -11,7 +11,8 @@ Same class name / ctor (`T5VQA_MMEncoderInput(m3ae_config)`), same state_dict pr
     padded to 512 rows, all-ones attention mask (:159-178) -- the padding rows are attended, as in the reference;
   * tokenisation happens outside: `batch["t5_labels"]` (int64 [B, T], pad 0, eos 1) or a `tokenizer` callable;
     "question:" is ids [822, 10] (the t5-small SentencePiece ids; not verifiable offline);
-  * beam-search `generate` for the per-step string metrics (:252-284) is not on the training hot path.
+  * beam-search `generate` (t5.py) serves the inference / test branch (:207-218); the extra `generate` the reference runs
+    inside every TRAINING step for its string metrics (:252-284) is not executed (metrics are out of scope).
 """
 import torch
 import torch.nn as nn
@@ -111,6 +112,10 @@ class T5VQA_MMEncoderInput(_Base):
         if self.store is None:
             raise RuntimeError("call finalize(device) before the first forward")
         inputs = self.prepare_inputs(batch)
+        if len(self.current_tasks) == 0 or test:  # inference / test: beam search (:207-218)
+            with torch.no_grad():
+                enc = self.t5.encoder(inputs["inputs_embeds"])
+            return {"generated_ids": self.t5.generate(enc, num_beams=4, max_length=self.max_answer_length)}
         out = self.t5(inputs["inputs_embeds"], self.labels_of(batch))
         return {"vqa_loss": out.loss, "vqa_logits": out.logits}
 

@@ -175,8 +175,7 @@ class T5Stack(nn.Module):
 
 class T5ForConditionalGeneration(nn.Module):
     """Encoder + teacher-forced decoder + tied LM head + cross-entropy (HF T5ForConditionalGeneration.forward with
-    `encoder_outputs` / `inputs_embeds` and `labels`).  Generation (beam search) is not on the training hot path and is
-    not provided."""
+    `encoder_outputs` / `inputs_embeds` and `labels`), and beam-search `generate`."""
 
     def __init__(self, name_or_dims="t5-small", vocab_size=32128):
         super().__init__()
@@ -202,6 +201,82 @@ class T5ForConditionalGeneration(nn.Module):
         table = ops.compute_weight(w) if dtype == torch.bfloat16 else w
         B, T = ids.shape
         return ops.EmbedRowsFn.apply(ids.reshape(-1), w, table).view(B, T, -1)
+
+    @torch.no_grad()
+    def next_token_logits(self, enc, prefix):
+        """Decoder over the whole prefix (no KV cache yet: T <= 12 here) -> logits of the last position, fp32."""
+        dec = self.decoder(self.embed(prefix, enc.dtype), enc)
+        last = dec[:, -1].contiguous()
+        return ops.linear(last, self.shared.weight, None, alpha=self.config.d_model ** -0.5).float()
+
+    @torch.no_grad()
+    def generate(self, enc, num_beams=4, max_length=12, eos_token_id=1, pad_token_id=0, length_penalty=1.0,
+                 len_offset=0):
+        """HF `generate(encoder_outputs=..., num_beams, early_stopping=True, max_length)` as the reference calls it
+        (m3ae_t5_mm_encoder_input.py:209-218,252-260): transformers-4.6.0 `beam_search` + `BeamSearchScorer`
+        semantics, restated in oracle/m3ae_oracle.py::t5_beam_search (pinned against the installed release's
+        `generate`; `len_offset` documents the one convention that changed between the two releases).
+        The model runs on the GPU; the per-step candidate bookkeeping (2 * beams scores and tokens per sample) is
+        host logic on one small device->host copy per step."""
+        B, nb, dev = enc.shape[0], num_beams, enc.device
+        enc_r = enc.repeat_interleave(nb, dim=0).contiguous()
+        ids = torch.full((B * nb, 1), self.config.decoder_start_token_id, dtype=torch.long, device=dev)
+        beam_scores = torch.zeros(B, nb, device=dev)
+        beam_scores[:, 1:] = -1e9
+        beam_scores = beam_scores.view(-1)
+        hyps = [[] for _ in range(B)]
+        done = [False] * B
+        cur_len = 1
+        while cur_len < max_length:
+            logp = torch.log_softmax(self.next_token_logits(enc_r, ids), dim=-1)
+            V = logp.shape[-1]
+            top_s, top_i = torch.topk((logp + beam_scores[:, None]).view(B, nb * V), 2 * nb, dim=1)
+            top_s, top_i = top_s.cpu(), top_i.cpu()
+            ids_h = ids.cpu()
+            nxt_scores = torch.zeros(B, nb)
+            nxt_tokens = torch.full((B, nb), pad_token_id, dtype=torch.long)
+            nxt_index = torch.zeros(B, nb, dtype=torch.long)
+            for b in range(B):
+                if done[b]:
+                    nxt_index[b] = b * nb
+                    continue
+                k = 0
+                for rank in range(2 * nb):
+                    tok, sc = int(top_i[b, rank] % V), float(top_s[b, rank])
+                    src = b * nb + int(top_i[b, rank] // V)
+                    if tok == eos_token_id:
+                        if rank >= nb:
+                            continue
+                        hyp = ids_h[src].clone()
+                        hyps[b].append((sc / (hyp.shape[-1] ** length_penalty), hyp))
+                        hyps[b] = sorted(hyps[b], key=lambda t: -t[0])[:nb]
+                    else:
+                        nxt_scores[b, k], nxt_tokens[b, k], nxt_index[b, k] = sc, tok, src
+                        k += 1
+                    if k == nb:
+                        break
+                done[b] = done[b] or len(hyps[b]) >= nb
+            beam_scores = nxt_scores.view(-1).to(dev)
+            ids = torch.cat([ids[nxt_index.view(-1).to(dev)], nxt_tokens.view(-1, 1).to(dev)], dim=1)
+            cur_len += 1
+            if all(done):
+                break
+        ids_h, scores_h = ids.cpu(), beam_scores.cpu()
+        out = []
+        for b in range(B):
+            if not done[b]:
+                for j in range(nb):
+                    hyp = ids_h[b * nb + j]
+                    hyps[b].append((float(scores_h[b * nb + j]) / ((hyp.shape[-1] - len_offset) ** length_penalty), hyp))
+                hyps[b] = sorted(hyps[b], key=lambda t: -t[0])[:nb]
+            out.append(hyps[b][0][1])
+        L = min(max(len(h) for h in out) + 1, max_length)
+        seq = torch.full((B, L), pad_token_id, dtype=torch.long)
+        for b, h in enumerate(out):
+            seq[b, : len(h)] = h
+            if len(h) < max_length:
+                seq[b, len(h)] = eos_token_id
+        return seq.to(dev)
 
     def forward(self, inputs_embeds, labels):
         enc = self.encoder(inputs_embeds)

@@ -591,3 +591,83 @@ def decoder_search(sd, enc, cls_id=101, sep_id=102, eos_id=None, pad_id=0, max_l
         if len(hit) > 0:
             seq[i, hit[0] + 1:] = pad_id
     return F.pad(seq, (0, max_len - seq.shape[1]), value=pad_id)
+
+
+# ------------------------------------------------------------------------------------------------
+# T5 beam-search generation.  The reference calls HF `generate(num_beams=4, early_stopping=True,
+# max_length=t5_max_length)` (m3ae_t5_mm_encoder_input.py:209-218,252-260; third party: transformers==4.6.0
+# `GenerationMixin.beam_search` + `BeamSearchScorer`).  Restated from the 4.6.0 algorithm: log-softmax scores added to the
+# running beam scores, top 2*beams candidates per sample, EOS candidates ranked inside the first `beams` become
+# finished hypotheses scored sum_logprobs / len(prefix) ** length_penalty (prefix = tokens so far INCLUDING the decoder
+# start token, EXCLUDING the EOS), a sample is done as soon as it holds `beams` hypotheses (early_stopping=True), open
+# beams are added at the end, the best hypothesis per sample is returned (+ EOS when shorter than max_length), padded.
+# The decoder re-runs the whole prefix every step here (no KV cache) -- same numbers, this is the checker.
+# ------------------------------------------------------------------------------------------------
+def t5_next_token_logits(sd, enc, prefix, heads):
+    dec = t5_decoder(sd, prefix, enc, heads)
+    return (dec[:, -1] * dec.shape[-1] ** -0.5) @ sd["t5.shared.weight"].t()
+
+
+def t5_beam_search(sd, enc, heads, num_beams=4, max_length=12, eos_id=1, pad_id=0, start_id=0, length_penalty=1.0,
+                   len_offset=0):
+    """len_offset = 0: transformers 4.6.0 (the reference's pin) divides an OPEN beam's log-probability at max_length by its
+    token count including the decoder start token; later releases (the one installed in the build container) exclude the
+    start token there (len_offset = 1) -- used only to pin this restatement against that release's `generate`.
+    EOS-terminated hypotheses are divided by the prefix length in both."""
+    B = enc.shape[0]
+    nb = num_beams
+    enc_r = enc.repeat_interleave(nb, dim=0)
+    ids = torch.full((B * nb, 1), start_id, dtype=torch.long)
+    beam_scores = torch.zeros(B, nb)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [[] for _ in range(B)]          # (score, tokens)
+    done = [False] * B
+    cur_len = 1
+    while cur_len < max_length:
+        logp = torch.log_softmax(t5_next_token_logits(sd, enc_r, ids, heads), dim=-1)
+        V = logp.shape[-1]
+        scores = (logp + beam_scores[:, None]).view(B, nb * V)
+        top_s, top_i = torch.topk(scores, 2 * nb, dim=1, largest=True, sorted=True)
+        nxt_scores = torch.zeros(B, nb)
+        nxt_tokens = torch.full((B, nb), pad_id, dtype=torch.long)
+        nxt_index = torch.zeros(B, nb, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                nxt_index[b] = b * nb
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                tok, sc, src = int(top_i[b, rank] % V), float(top_s[b, rank]), b * nb + int(top_i[b, rank] // V)
+                if tok == eos_id:
+                    if rank >= nb:
+                        continue
+                    hyp = ids[src].clone()
+                    hyps[b].append((sc / (hyp.shape[-1] ** length_penalty), hyp))
+                    hyps[b] = sorted(hyps[b], key=lambda t: -t[0])[:nb]
+                else:
+                    nxt_scores[b, k], nxt_tokens[b, k], nxt_index[b, k] = sc, tok, src
+                    k += 1
+                if k == nb:
+                    break
+            done[b] = done[b] or len(hyps[b]) >= nb      # early_stopping=True
+        beam_scores = nxt_scores.view(-1)
+        ids = torch.cat([ids[nxt_index.view(-1)], nxt_tokens.view(-1, 1)], dim=1)
+        cur_len += 1
+        if all(done):
+            break
+    out = []
+    for b in range(B):
+        if not done[b]:
+            for j in range(nb):
+                hyp = ids[b * nb + j]
+                hyps[b].append((float(beam_scores[b * nb + j]) / ((hyp.shape[-1] - len_offset) ** length_penalty), hyp))
+            hyps[b] = sorted(hyps[b], key=lambda t: -t[0])[:nb]
+        out.append(hyps[b][0][1])
+    L = min(max(len(h) for h in out) + 1, max_length)
+    seq = torch.full((B, L), pad_id, dtype=torch.long)
+    for b, h in enumerate(out):
+        seq[b, : len(h)] = h
+        if len(h) < max_length:
+            seq[b, len(h)] = eos_id
+    return seq

@@ -355,8 +355,50 @@ def run_decoder():
 
 
 
+GEN_EOS = (420, 764, 726, 442, 259, 1)
+
+
+def gen_t5_weights(sd):
+    """Deterministic T5 weights whose next-token distribution is neither a copy machine nor flat: block weights x 8,
+    tied embedding std 0.3 (shared by this script and the tests; values are regenerated, never stored)."""
+    synth.fill_deterministic(sd)
+    for k in sd:
+        if any(t in k for t in (".q.weight", ".k.weight", ".v.weight", ".o.weight", ".wi.weight", ".wo.weight")):
+            sd[k].mul_(8.0)
+    sd["t5.shared.weight"].copy_(synth.det_normal("t5.shared.weight", sd["t5.shared.weight"].shape, std=0.3))
+    return sd
+
+
+def run_t5_generate():
+    """beam-4 sequences of the third-party `generate` the reference calls
+    (m3ae_t5_mm_encoder_input.py:209-218), from the release installed here, on a tiny deterministic T5; several EOS ids so
+    that finished hypotheses, early stopping and length normalisation all occur."""
+    from transformers import T5Config, T5ForConditionalGeneration
+    from transformers.modeling_outputs import BaseModelOutput
+    res = {"eos_ids": np.array(GEN_EOS)}
+    for eos in GEN_EOS:
+        cfg = T5Config(vocab_size=1100, d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2, num_heads=8,
+                       dropout_rate=0.1, feed_forward_proj="relu", tie_word_embeddings=True, decoder_start_token_id=0,
+                       pad_token_id=0, eos_token_id=eos)
+        cfg._attn_implementation = "eager"
+        m = T5ForConditionalGeneration(cfg).eval()
+        sd = gen_t5_weights({"t5." + k: v for k, v in m.state_dict().items()})
+        m.load_state_dict({k[3:]: v for k, v in sd.items()})
+        m.tie_weights()
+        x = synth.det_normal("gen_in", (12, 8, 512), std=1.0)
+        with torch.no_grad():
+            enc = m.encoder(inputs_embeds=x, attention_mask=torch.ones(12, 8, dtype=torch.long)).last_hidden_state
+            out = m.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc.clone()), max_length=8, num_beams=4,
+                             early_stopping=True, pad_token_id=0, eos_token_id=eos, return_dict_in_generate=True)
+        res[f"seq_{eos}"] = out.sequences.numpy()
+        res["enc"] = enc.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_t5_generate.npz"), **res)
+    print("[t5-generate]", {e: res[f"seq_{e}"][:2].tolist() for e in GEN_EOS[:2]})
+
+
+
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder", "t5gen"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -366,6 +408,8 @@ def main():
         run_t5()
     if "decoder" in what:
         run_decoder()
+    if "t5gen" in what:
+        run_t5_generate()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
 

@@ -43,3 +43,26 @@ def full_batch(B=2):
 
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)
+
+
+def gen_t5_weights(sd):
+    """Same recipe as oracle/make_golden.py::gen_t5_weights (kept in sync by the fixture test)."""
+    from m3ae_amd import synth
+    synth.fill_deterministic(sd)
+    for k in sd:
+        if any(t in k for t in (".q.weight", ".k.weight", ".v.weight", ".o.weight", ".wi.weight", ".wo.weight")):
+            sd[k].mul_(8.0)
+    sd["t5.shared.weight"].copy_(synth.det_normal("t5.shared.weight", sd["t5.shared.weight"].shape, std=0.3))
+    return sd
+
+
+def canon_generated(seq, eos):
+    """Sequences up to and including the first EOS after the start token (what follows is padding, whose id differs
+    between transformers releases)."""
+    out = []
+    for r in seq:
+        r = [int(t) for t in r]
+        if eos in r[1:]:
+            r = r[: r.index(eos, 1) + 1]
+        out.append(r)
+    return out

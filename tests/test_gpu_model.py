@@ -195,6 +195,7 @@ def test_tiny_t5_generative_head_against_reference_fixture(mode):
     assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(
         n for n in g["trainable_names"].tolist() if not n.startswith("feature_projection"))
     m.store.zero_grad()
+    m.current_tasks = ["vqa"]  # training branch (an empty task list selects generation, as in the reference)
     out = m(b)
     loss = out["vqa_loss"]
     logits = out["vqa_logits"].detach().float().cpu().numpy()
@@ -395,3 +396,31 @@ def test_input_pipeline_device_tail_and_trainer_on_arrow_data(tmp_path):
              f"log_dir={tmp_path}", "seed=2"] + tiny)
     out = trainer.run(argv, tokenizer=tok)
     assert out["global_step"] == 3 and np.isfinite(out["test"])
+
+
+@pytest.mark.parametrize("len_offset", [0, 1])
+def test_t5_generate_matches_oracle_and_third_party(len_offset):
+    """`T5ForConditionalGeneration.generate` (decoder on the GPU kernels, fp32) against the CPU restatement
+    for both length conventions, and for len_offset=1 against the third-party sequences of the fixture."""
+    from m3ae_amd.modules.t5 import T5ForConditionalGeneration
+    from m3ae_amd.param_store import ParamStore, group_hparams_decoder, param_group_of_decoder
+    from oracle_util import canon_generated, gen_t5_weights
+    g = load_golden("tiny_t5_generate.npz")
+    m = T5ForConditionalGeneration(dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2,
+                                        num_heads=8), 1100)
+    sd = gen_t5_weights({"t5." + k: v for k, v in m.state_dict().items()})
+    m.load_state_dict({k[3:]: v for k, v in sd.items()})
+    cfg = tiny_config(compute_dtype="fp32")
+    ParamStore(m, cfg, "cuda", torch.float32, m.weight_units, group_fn=param_group_of_decoder,
+               hparams_fn=group_hparams_decoder)
+    m.eval()
+    enc = torch.from_numpy(g["enc"]).cuda()
+    sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    for eos in g["eos_ids"].tolist():
+        mine = m.generate(enc, num_beams=4, max_length=8, eos_token_id=eos, len_offset=len_offset)
+        with torch.no_grad():
+            ref = O.t5_beam_search(sd_cpu, torch.from_numpy(g["enc"]), 8, num_beams=4, max_length=8, eos_id=eos,
+                                   len_offset=len_offset)
+        assert mine.cpu().tolist() == ref.tolist(), eos
+        if len_offset == 1:
+            assert canon_generated(mine.cpu().tolist(), eos) == canon_generated(g[f"seq_{eos}"].tolist(), eos), eos

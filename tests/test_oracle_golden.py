@@ -167,3 +167,28 @@ def test_tiny_decoder_head_matches_reference():
     with torch.no_grad():
         greedy = O.decoder_search({k: v.detach() for k, v in sd.items()}, enc, max_len=16)
     np.testing.assert_array_equal(greedy.numpy(), g["greedy"])
+
+
+def _gen_sd():
+    from m3ae_amd.modules.t5 import T5ForConditionalGeneration
+    from oracle_util import gen_t5_weights
+    with torch.device("meta"):
+        m = T5ForConditionalGeneration(dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2,
+                                            num_heads=8), 1100)
+    sd = {"t5." + k: torch.empty(v.shape, dtype=torch.float32) for k, v in m.state_dict().items()}
+    return gen_t5_weights(sd)
+
+
+def test_t5_beam_search_matches_third_party_generate():
+    """the beam-search restatement against sequences produced by the installed transformers `generate`
+    (num_beams=4, early_stopping=True) on the same deterministic tiny T5, six EOS ids (60+ finished-hypothesis events).
+    The installed release normalises open beams by the generated length (len_offset=1); 4.6.0 -- the reference's pin and
+    the product default -- includes the start token (len_offset=0), which changes 8 of these 72 results."""
+    from oracle_util import canon_generated
+    g = load_golden("tiny_t5_generate.npz")
+    sd = _gen_sd()
+    enc = torch.from_numpy(g["enc"])
+    with torch.no_grad():
+        for eos in g["eos_ids"].tolist():
+            mine = O.t5_beam_search(sd, enc, 8, num_beams=4, max_length=8, eos_id=eos, len_offset=1)
+            assert canon_generated(mine.tolist(), eos) == canon_generated(g[f"seq_{eos}"].tolist(), eos), eos
