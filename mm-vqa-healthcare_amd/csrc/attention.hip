@@ -718,7 +718,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(qp, ks, h); dof[ks] = row_frag(dop, ks, h); }
     const float lse = a.lse[(b * a.H + head) * a.lse_stride + qrow];
-    const float dlt = a.delta[(b * a.H + head) * a.lse_stride + qrow];
+    // delta[q] = sum_d dO[q][d] O[q][d]: this lane already holds half of its row of dO (the MFMA fragments); the matching
+    // half of O is fetched once, the two halves meet through a lane swap, and the value is published for the dK/dV kernel
+    // (which runs after this one) -- the stand-alone delta pass re-read dO and O from HBM for every attention call
+    float dlt = 0.f;
+    {
+        const bf16_t* op = a.o + b * a.o_sb + qrow * a.o_sl + head * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const s16x8 of = row_frag(op, ks, h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt = fmaf(bf2f((bf16_t)of[j]), bf2f((bf16_t)dof[ks][j]), dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (h == 0 && active && qi < a.Lq) a.delta[(b * a.H + head) * a.lse_stride + qi] = dlt;
+    }
 
     const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
     const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
@@ -1144,10 +1158,12 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         if (!bf16_layout_ok(d, true)) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
         const int64_t total = d.B * d.Lq * d.H;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
+        const bool coop = g_attn_coop || a.has_drop;
+        if (!coop)  // the cooperative dQ kernel computes (and publishes) delta itself
+            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        if (g_attn_coop || a.has_drop) {
+        if (coop) {
             int rc = 0;
             ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );
             ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );

@@ -247,8 +247,10 @@ extern "C" int m3ae_layernorm_fwd(const void* x, const float* gamma, const float
 }
 
 extern "C" int64_t m3ae_layernorm_bwd_blocks(int64_t M) {
+    // 1024 workgroups x 4 waves = 4 waves per SIMD on 256 CUs (the kernel's register footprint allows exactly that): a
+    // wave works through its rows strictly one after the other, so resident waves are what hides the HBM latency
     int64_t n = cdiv(M, 4);
-    return n < 512 ? n : 512;
+    return n < 1024 ? n : 1024;
 }
 
 extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
