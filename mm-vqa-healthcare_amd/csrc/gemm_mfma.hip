@@ -724,7 +724,9 @@ static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
-        const bool big = a.M >= 4096 && a.N >= 512;
+        // the 256 x 256 ping-pong kernel runs one workgroup per CU: it needs at least two full rounds of tiles to beat the
+        // 128 x 128 kernel (text stream at per-GPU batch 256, M = 8192: 96 .. 384 tiles -> 18 vs 25 us, 47 vs 66 us)
+        const bool big = cdiv(a.M, 256) * cdiv(a.N, 256) >= 512;
         // ping-pong kernel (variant 7): 1232 / 1340 TF/s at 4096^3 / 8192^3, +3..10 % over the 2-stage kernel on the
         // path's own shapes (profiles/r01_gemm_shapes.log)
         if (big) return launch_nt_pp<EPI>(a, s);

@@ -11,7 +11,7 @@ from m3ae_amd import _lib, ops  # noqa: E402
 B = int(os.environ.get("B", 64))
 VARS = tuple(int(v) for v in os.environ.get('VARS', '0,4,6').split(','))
 M = B * 577
-NT_SHAPES = [(M, 3072, 768)] if os.environ.get('TN_ONLY') else [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768),
+NT_SHAPES = [(M, 3072, 768)] if os.environ.get('TN_ONLY') else [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768), (B * 32, 768, 3072), (B * 32, 2304, 768),
              (4096, 4096, 4096), (8192, 8192, 8192)]
 TN_SHAPES = [(M, 768, 768), (M, 2304, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768)]
 
