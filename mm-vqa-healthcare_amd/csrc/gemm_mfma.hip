@@ -942,8 +942,9 @@ static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
     const int64_t tiles = (d.M / BM_) * (d.N / BN_);
     const int64_t ksteps = cdiv(d.K, 64);
     const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
+    static const int64_t min_steps = getenv("M3AE_TN_MINSTEPS") ? atoi(getenv("M3AE_TN_MINSTEPS")) : 16;  // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us)
     int64_t splits = target / tiles;
-    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits > ksteps / min_steps) splits = ksteps / min_steps;
     if (splits < 1) splits = 1;
     if (!d.accumulate) splits = 1;
     const int64_t steps_per = cdiv(ksteps, splits);
