@@ -49,7 +49,11 @@ def main():
                          "parameter: 5.15 GB / 4.51 GB per step measured vs 5.15 / 4.51 expected); fabric-side counters, "
                          "Infinity-Cache hits included",
                "gemm_nt_pp_kernel": summary(fetch, write, "gemm_nt_pp_kernel"),
+               "gemm_nt_bf16_kernel": summary(fetch, write, "gemm_nt_bf16_kernel"),
+               "gemm_tn_pp_kernel": summary(fetch, write, "gemm_tn_pp_kernel"),
                "gemm_tn_bf16_kernel": summary(fetch, write, "gemm_tn_bf16_kernel"),
+               "attn_bwd_dkdv_coop_kernel": summary(fetch, write, "attn_bwd_dkdv_coop_kernel"),
+               "ln_bwd_kernel": summary(fetch, write, "ln_bwd_kernel"),
                "attn_fwd_coop_kernel": summary(fetch, write, "attn_fwd_coop_kernel"),
                "adamw_kernel": summary(fetch, write, "adamw_kernel")}
         with open(js[0], "w") as f:
