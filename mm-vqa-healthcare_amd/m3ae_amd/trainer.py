@@ -170,12 +170,17 @@ class Trainer:
         tot, cnt = torch.zeros((), device=self.device), 0
         with torch.no_grad():
             for batch in self.dm.val_batches():
+                n = batch["text_ids"].shape[0]
+                ret = None
                 if hasattr(self.model, "vqa_head_forward"):
                     self.model.set_task()
                     ret = self.model(batch, test=True)
+                if ret is not None and "vqa_logits" in ret:
                     s, n = vqa_score(ret["vqa_logits"], ret["vqa_targets"])
-                else:  # generator heads: negative teacher-forced loss as the monitored quantity
-                    s, n = -self._loss(batch).float() * batch["text_ids"].shape[0], batch["text_ids"].shape[0]
+                elif ret is not None:   # pre-training objectives: negative summed loss as the monitored quantity
+                    s = -sum(v.float() for k, v in ret.items() if k.endswith("_loss")) * n
+                else:                   # generator heads: negative teacher-forced loss
+                    s = -self._loss(batch).float() * n
                 tot += s
                 cnt += n
         t = torch.stack([tot, torch.tensor(float(cnt), device=self.device)])

@@ -424,3 +424,19 @@ def test_t5_generate_matches_oracle_and_third_party(len_offset):
         assert mine.cpu().tolist() == ref.tolist(), eos
         if len_offset == 1:
             assert canon_generated(mine.cpu().tolist(), eos) == canon_generated(g[f"seq_{eos}"].tolist(), eos), eos
+
+
+def test_trainer_shim_pretrain_objectives(tmp_path):
+    """configs[3] recipe through the entry point: MLM + MIM + ITM on synthetic pre-training batches (three `infer`
+    passes per step, masked image stream, vocabulary GEMM), a few optimizer steps."""
+    from m3ae_amd import trainer
+    tiny = ("image_size=64 hidden_size=128 num_heads=2 num_top_layer=2 input_image_embed_size=128 "
+            "input_text_embed_size=128 vocab_size=1000 vit_width=128 vit_layers=3 text_hidden=128 text_layers=2 "
+            "text_heads=2 text_inter=512 mim_decoder_hidden_size=128 mim_decoder_num_layers=2 mim_decoder_num_heads=2 "
+            "mim_layer=1 max_text_len=32").split()
+    argv = (["with", "data_root=synthetic", "num_gpus=1", "num_nodes=1", "task_pretrain_m3ae", "clip16", "text_roberta",
+             "per_gpu_batchsize=4", "batch_size=4", "max_steps=3", "learning_rate=0.0005", "synthetic_train_samples=16",
+             "synthetic_val_samples=4", f"log_dir={tmp_path}", "seed=7", "precision=32"] + tiny)
+    out = trainer.run(argv)
+    assert out["global_step"] == 3
+    assert np.isfinite([h[1] for h in out["history"]]).all()
