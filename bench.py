@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("M3AE_BENCH_BATCH", 256)), help="per-GPU batch")
-    ap.add_argument("--head", choices=["cls", "t5"], default="cls",
+    ap.add_argument("--head", choices=["cls", "t5", "pretrain"], default="cls",
                     help="cls: configs[1] full fine-tune with the classification head (default, the timed metric); "
                          "t5: configs[2] frozen M3AE + T5 generative head (main_t5_m3ae.py recipe)")
     ap.add_argument("--t5", default="t5-small", help="t5-small (reference-faithful) | t5-base (BASELINE configs[2])")
@@ -100,6 +100,10 @@ def main():
     torch.set_num_threads(host_cores())
     log(f"rank {rank}/{world} on {dev}: building model")
     cfg = finetune_vqa_rad_config(compute_dtype="bf16", t5_model_name=args.t5)
+    if args.head == "pretrain":  # configs[3]: MLM + MIM + ITM @384, 64 text tokens (task_pretrain_m3ae, roberta vocabulary)
+        from m3ae_amd.config import compose
+        cfg = compose("task_pretrain_m3ae", "clip16", "text_roberta", image_size=384, max_text_len=64, compute_dtype="bf16")
+        args.no_cpu_baseline = args.no_roofline = True
     if args.head == "t5":
         from m3ae_amd.modules import T5VQA_MMEncoderInput
         model = T5VQA_MMEncoderInput(cfg)
@@ -117,7 +121,8 @@ def main():
 
     log("model resident; generating synthetic batch")
     B = args.batch
-    batch = to_dev(synth.synthetic_batch(B, text_len=32, image_size=384, rank=rank), dev)
+    batch = to_dev(synth.synthetic_batch(B, text_len=cfg["max_text_len"], image_size=384, rank=rank,
+                                         pretrain=args.head == "pretrain"), dev)
     batch["vqa_targets"] = build_vqa_targets(batch, cfg["vqa_label_size"], dev)
     if args.head == "t5":
         lab = synth.det_randint("t5_labels", 2, 32128, (B, 6), salt=31 + rank)
@@ -265,12 +270,16 @@ def main():
     if rank == 0:
         line = {
             "metric": "image-question pairs/sec, M3AE-base fine-tune step (fwd+bwd+AdamW) @384px" if args.head == "cls"
-            else f"image-question pairs/sec, M3AE-base(frozen)+{args.t5} generative-head fine-tune step @384px",
+            else ("image-text pairs/sec, M3AE-base pre-training step (MLM + MIM + ITM, fwd+bwd+AdamW) @384px"
+                  if args.head == "pretrain" else
+                  f"image-question pairs/sec, M3AE-base(frozen)+{args.t5} generative-head fine-tune step @384px"),
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[1]: M3AE-base (ViT-B/16 + RoBERTa-base + 6 co-attention layers) VQA-RAD "
                                     "classification fine-tune, 384x384, 32 text tokens, 498 answers") if args.head == "cls"
+                       else ("configs[3]: M3AE-base pre-training, three infer passes per step (MLM, MIM at 75 % masking, ITM), "
+                             "384x384, 64 text tokens, RoBERTa vocabulary 50265") if args.head == "pretrain"
                        else (f"configs[2] recipe: frozen M3AE-base forward + {args.t5} encoder (512 padded tokens) / "
                              "teacher-forced decoder / tied LM head, top-4 encoder + top-4 decoder attention blocks "
                              "trainable (main_t5_m3ae.py)"),

@@ -43,7 +43,7 @@ class MLMHead(nn.Module):
         t = self.transform
         h = ops.linear(x, t.dense.weight, t.dense.bias, act=ops.ACT_GELU)
         h = ops.layer_norm(h, t.LayerNorm.weight, t.LayerNorm.bias, t.LayerNorm.eps)
-        return ops.linear(h, self.decoder.weight, self.bias)
+        return ops.vocab_linear(h, self.decoder.weight, self.bias)
 
     def weight_units(self):
         return [self.transform.dense.weight, self.decoder.weight]

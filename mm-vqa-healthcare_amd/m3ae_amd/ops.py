@@ -1004,26 +1004,90 @@ class XentFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels):
-        x = logits.contiguous().view(-1, logits.shape[-1])
-        rows, Cc = x.shape
+        # rows may be strided (a [..., :V] view of vocabulary-padded logits, see VocabProjFn): no compaction copy
+        x = logits
+        Cc = x.shape[-1]
+        uniform = x.dim() >= 2 and x.stride(-1) == 1 and all(
+            x.stride(i) == x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 2))
+        if not uniform:
+            x = x.contiguous()
+        ld = x.stride(-2) if x.dim() >= 2 else Cc
+        rows = x.numel() // Cc
         lab = labels.contiguous().view(-1)
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         ws = torch.empty(4, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
-        check(_lib.lib().m3ae_xent(_p(x), _p(lab), _p(loss), _p(dx), _p(ws), rows, Cc, Cc, 1.0, _dt(x), _stream()),
+        dx = (torch.zeros if ld != Cc else torch.empty)((rows, ld), dtype=x.dtype, device=x.device)
+        check(_lib.lib().m3ae_xent(_p(x), _p(lab), _p(loss), _p(dx), _p(ws), rows, Cc, ld, 1.0, _dt(x), _stream()),
               "m3ae_xent")
         ctx.save_for_backward(dx)
-        ctx.shape = logits.shape
+        ctx.shape, ctx.cols = logits.shape, Cc
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
-        return (dx * g.to(dx.dtype)).view(ctx.shape), None
+        d = dx * g.to(dx.dtype)
+        return d.view(*ctx.shape[:-1], dx.shape[-1])[..., :ctx.cols], None
 
 
 def cross_entropy(logits, labels):
     return XentFn.apply(logits, labels)
+
+
+class VocabProjFn(torch.autograd.Function):
+    """logits = x . W^T + b for a vocabulary that is not a multiple of 128 (RoBERTa: 50265), perf mode.  The MFMA
+    kernels need N % 4 == 0 (forward), K % 64 == 0 (dgrad) and N1 % 128 == 0 (wgrad); the odd size would send all three
+    to the generic kernel (14 % of a pre-training step).  Zero-padded bf16 operand copies [Vp, K] / [K, Vp] (Vp = V rounded
+    up to 128, refreshed from the weight's bf16 shadows on every call: two 77-MB copies) keep them on the MFMA path.
+    Returns PADDED logits [..., Vp] (pad columns = 0); callers slice [..., :V] (ops.vocab_linear)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2, M, K, ldx = _rows(x)
+        V = weight.shape[0]
+        Vp = (V + 127) // 128 * 128
+        st = getattr(weight, "_vocab_pad", None)
+        if st is None:
+            dev = x.device
+            st = (torch.zeros((Vp, K), dtype=torch.bfloat16, device=dev), torch.zeros((K, Vp), dtype=torch.bfloat16, device=dev),
+                  torch.zeros(Vp, dtype=torch.float32, device=dev))
+            weight._vocab_pad = st
+        Wp, WpT, bp = st
+        Wp[:V].copy_(compute_weight(weight))
+        WpT[:, :V].copy_(weight.m3ae_t)
+        if bias is not None:
+            bp[:V].copy_(bias.detach())
+        y, _ = mm_nt(x2, ldx, M, Wp, bias=bp)
+        ctx.save_for_backward(x2)
+        ctx.meta = (weight, bias, M, K, V, Vp, ldx, x.shape)
+        return y.view(*x.shape[:-1], Vp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        weight, bias, M, K, V, Vp, ldx, xshape = ctx.meta
+        _, WpT, _ = weight._vocab_pad
+        dy2 = dy.contiguous().view(M, Vp)
+        dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+        gemm(dy2, Vp, 1, WpT, 1, Vp, dx, K, M, K, Vp)                       # dX = dY . W   (K-contiguous transposed copy)
+        if weight.requires_grad:
+            dWp = torch.zeros((Vp, K), dtype=torch.float32, device=dy2.device)
+            dbp = torch.zeros(Vp, dtype=torch.float32, device=dy2.device)
+            gemm(dy2, 1, Vp, x2, ldx, 1, dWp, K, Vp, K, M, accumulate=True, a_rowsum=dbp)   # dW = dY^T . X  (+ column sums)
+            _grad_buf(weight).add_(dWp[:V])
+            _done(weight)
+            if bias is not None and bias.requires_grad:
+                _grad_buf(bias).add_(dbp[:V])
+                _done(bias)
+        return dx.view(xshape), None, None
+
+
+def vocab_linear(x, weight, bias):
+    """Vocabulary projection (MLM head, prediction_heads.py:33): MFMA path for any vocabulary size in perf mode."""
+    V = weight.shape[0]
+    if x.dtype == torch.bfloat16 and V % 128 != 0 and getattr(weight, "m3ae_t", None) is not None:
+        return VocabProjFn.apply(x, weight, bias)[..., :V]
+    return linear(x, weight, bias)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -470,3 +470,36 @@ def test_gemm_wgrad_tn_pingpong_variant(M, N, K):
             close(db, refb, 1e-4, 1e-3 * math.sqrt(M), msg=f"bias grad pp iter {it}")
     finally:
         _lib.lib().m3ae_set_tuning(1, -1)
+
+
+def test_vocab_projection_padded_mfma_path_for_odd_vocabulary():
+    """MLM head with a vocabulary that is no multiple of 128 (RoBERTa: 50265): zero-padded operand copies keep forward,
+    dgrad and wgrad on the MFMA kernels; logits view + strided cross-entropy + gradients against torch."""
+    from m3ae_amd import synth
+    from m3ae_amd.modules.prediction_heads import MLMHead
+    from m3ae_amd.param_store import ParamStore
+    V, D, B, S = 1001, 128, 3, 50
+    head = MLMHead(D, V)
+    synth.fill_deterministic(head)
+    head.bias.data = 0.1 * torch.randn(V)
+    cfg = dict(learning_rate=1e-3, weight_decay=0.01, lr_multiplier_head=1, lr_multiplier_multi_modal=1)
+    store = ParamStore(head, cfg, "cuda", torch.bfloat16, weight_units=head.weight_units)
+    store.zero_grad()
+    x = rnd(B, S, D, dtype=torch.bfloat16, seed=90).requires_grad_(True)
+    labels = torch.randint(0, V, (B, S), device=dev())
+    labels[0, :7] = -100
+    logits = ops.vocab_linear(x, head.decoder.weight, head.bias)
+    assert logits.shape == (B, S, V) and logits.stride(-2) == 1024 and ops.last_gemm_path().startswith("mfma")
+    loss = ops.cross_entropy(logits, labels)
+    loss.backward()
+    w = head.decoder.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    bb = head.bias.detach().clone().requires_grad_(True)
+    xr = x.detach().float().requires_grad_(True)
+    lr = xr @ w.t() + bb
+    lossr = torch.nn.functional.cross_entropy(lr.view(-1, V), labels.view(-1), ignore_index=-100)
+    lossr.backward()
+    close(logits, lr, 1e-2, 2e-2, msg="vocab logits")
+    assert abs(loss.item() - lossr.item()) < 2e-3 * lossr.item()
+    close(x.grad, xr.grad, 3e-2, 2e-2 * xr.grad.abs().max().item(), msg="dx")
+    close(head.decoder.weight.grad, w.grad, 3e-2, 2e-2 * w.grad.abs().max().item(), msg="dW")
+    close(head.bias.grad, bb.grad, 3e-2, 2e-2 * bb.grad.abs().max().item(), msg="db")
