@@ -440,3 +440,45 @@ def test_trainer_shim_pretrain_objectives(tmp_path):
     out = trainer.run(argv)
     assert out["global_step"] == 3
     assert np.isfinite([h[1] for h in out["history"]]).all()
+
+
+def test_full_size_bench_batch_properties():
+    """Size-independent properties at the BENCH's per-GPU batch scale (configs[1] dims, bf16, B = 64, the large-tile
+    kernels): forward determinism bit for bit, sample independence (a sample's logits do not depend on its batch mates
+    or its position), loss / gradient linearity in the loss scale, and agreement of the first two samples with the
+    reference fixture."""
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    m = build(cfg, torch.bfloat16)
+    B = 64
+    b = to_dev(synth.synthetic_batch(B, text_len=32, image_size=384, rank=0))
+    m.set_task()
+    with torch.no_grad():
+        l1 = m(b)["vqa_logits"].float()
+        l2 = m(b)["vqa_logits"].float()
+    assert torch.equal(l1, l2)
+    perm = torch.arange(B - 1, -1, -1, device="cuda")
+    bp = dict(b)
+    bp["image"] = [b["image"][0][perm]]
+    for k in ("text_ids", "text_masks", "text_labels"):
+        bp[k] = b[k][perm]
+    bp["vqa_labels"] = [b["vqa_labels"][i] for i in perm.tolist()]
+    bp["vqa_scores"] = [b["vqa_scores"][i] for i in perm.tolist()]
+    with torch.no_grad():
+        lp = m(bp)["vqa_logits"].float()
+    assert torch.equal(lp[perm], l1)        # every output row is reduced in the same order wherever the sample sits
+    # the fixture's two samples are the first two of this batch (same generator, rank 0): bf16 bound on the logits
+    g = load_golden("full_vqa.npz")
+    b2 = to_dev(full_batch())
+    if torch.equal(b2["text_ids"], b["text_ids"][:2]):
+        assert np.abs(l1[:2].cpu().numpy() - g["logits"]).max() < 0.05
+    # linearity: d(2 L) = 2 dL (fp32 atomics in the split-K wgrad: tolerance, not bit equality)
+    m.store.zero_grad()
+    loss = m(b)["vqa_loss"]
+    loss.backward()
+    g1 = m.store.grad.clone()
+    m.store.zero_grad()
+    (2.0 * m(b)["vqa_loss"]).backward()
+    g2 = m.store.grad
+    rel = ((g2 - 2.0 * g1).double().norm() / (2.0 * g1).double().norm()).item()
+    assert rel < 1e-3, rel
+    assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
