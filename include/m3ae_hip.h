@@ -27,7 +27,8 @@ extern "C" {
 #define M3AE_ABI_VERSION 1
 
 enum { M3AE_F32 = 0, M3AE_BF16 = 1 };
-enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TANH = 3, M3AE_ACT_RELU = 4 };
+enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TANH = 3, M3AE_ACT_RELU = 4,
+       M3AE_ACT_MULAUX = 5 /* dact only: dact_aux already holds act'(pre) (written by a forward with preact_grad) */ };
 enum { M3AE_ERR_ARG = -1, M3AE_ERR_UNSUPPORTED = -2, M3AE_ERR_ALIGN = -3, M3AE_ERR_WORKSPACE = -4 };
 
 int m3ae_abi_version(void);
@@ -42,7 +43,8 @@ const char* m3ae_last_gemm_path(void);
  *   and their autograd backward (dgrad / wgrad).
  *
  *   C[b1][b2][m][n] = epi( alpha * sum_k A[b1][b2][m][k] * B[b1][b2][k][n] )
- *   epi(x): x += bias[n]; if (preact) preact[m][n] = x; x = act(x); if (residual) x += residual[m][n];
+ *   epi(x): x += bias[n]; if (preact) preact[m][n] = preact_grad ? act'(x) : x; x = act(x);
+ *           if (residual) x += residual[m][n];
  *           if (dact_aux) x *= act'(dact_aux[m][n]) (derivative of `dact` at the saved pre-activation);
  *           if (accumulate) C += x else C = x.
  * Strides are in ELEMENTS.  preact / residual / dact_aux share C's strides and dtype.
@@ -71,6 +73,9 @@ typedef struct {
     float* a_rowsum;       /* optional fp32 [M]: a_rowsum[m] += sum_k A[m][k] (bias gradient fused into wgrad) */
     float dropout_p;       /* > 0: x = dropout(x) after bias/activation, BEFORE the residual add (nn.Dropout of */
     uint64_t dropout_seed; /*      bert_model.py:362,440); keep-mask = m3ae counter hash of (seed, m * N + n)     */
+    int32_t preact_grad;   /* forward: store act'(pre-activation) in `preact` instead of the pre-activation: the erf / exp
+                            * terms are already in registers there, and the backward GEMM (dact = M3AE_ACT_MULAUX) then
+                            * multiplies by the saved derivative instead of re-evaluating it (its epilogue was VALU-bound) */
 } m3ae_gemm_desc;
 int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
 

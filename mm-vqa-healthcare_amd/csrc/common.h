@@ -64,6 +64,7 @@ DEVINL float act_bwd(float x, int act) {
             float t = tanhf(x);
             return 1.0f - t * t;
         }
+        case M3AE_ACT_MULAUX: return x;  // the saved value IS the derivative
         case M3AE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
         default: return 1.0f;
     }
@@ -139,6 +140,30 @@ template <int N> DEVINL void act_fwd_fast_n(float* x, int act) {
     } else {
 #pragma unroll
         for (int t = 0; t < N; ++t) x[t] = act_fwd_fast(x[t], act);
+    }
+}
+// x <- act(x), d <- act'(x): one evaluation of the erf / sigmoid terms serves both
+template <int N> DEVINL void act_fwd_grad_fast_n(float* x, float* d, int act) {
+    if (act == M3AE_ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < N; t += 2) {
+            f32x2 c, p, v = {x[t], x[t + 1]};
+            gelu_terms_fast2(v, c, p);
+            const f32x2 g = __builtin_elementwise_fma(v, p, c);
+            v = v * c;
+            x[t] = v[0]; x[t + 1] = v[1];
+            d[t] = g[0]; d[t + 1] = g[1];
+        }
+    } else if (act == M3AE_ACT_QUICKGELU) {
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546695959f * x[t]));
+            d[t] = s * fmaf(1.702f * x[t], 1.0f - s, 1.0f);
+            x[t] = x[t] * s;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < N; ++t) { d[t] = act_bwd(x[t], act); x[t] = act_fwd(x[t], act); }
     }
 }
 template <int N> DEVINL void act_bwd_mul_fast_n(float* x, const float* pre, int act) {  // x *= act'(pre)

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
             int64_t off = gm * d.c_sm + gn * d.c_sn;
             float x = acc[i][j] * d.alpha;
             if (d.bias) x += d.bias[gn];
-            if (P) Elem<TC>::st(P + off, x);
+            if (P) Elem<TC>::st(P + off, d.preact_grad ? act_bwd(x, d.act) : x);
             x = act_fwd(x, d.act);
             if (d.dropout_p > 0.f) x = drop_apply(drop, (uint64_t)(gm * drop_ld(d.N) + gn), x);
             if (R) x += Elem<TC>::ld(R + off);

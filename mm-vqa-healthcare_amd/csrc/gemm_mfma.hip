@@ -27,7 +27,7 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;    // 32 KiB
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 64 KiB
 
 // epilogue classes (template parameter: keeps erf/exp code out of the kernels that do not need it)
-enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_QGELU = 2, EPI_DGELU = 3, EPI_DQGELU = 4, EPI_ANY = 5 };
+enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_QGELU = 2, EPI_DGELU = 3, EPI_DQGELU = 4, EPI_ANY = 5, EPI_DMUL = 6 };
 
 struct MfmaArgs {
     const bf16_t* A; int64_t lda;
@@ -40,6 +40,7 @@ struct MfmaArgs {
     const float* bias;
     int act;
     void* preact;
+    int preact_grad;  // store act'(pre) instead of pre
     const void* residual;
     const void* dact_aux;
     int dact;
@@ -138,9 +139,15 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
         for (int t = 0; t < 4; ++t) x[t] += y[t];
     }
     if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
-        if (a.preact) Vec4<TC>::st((TC*)a.preact + off, x);
         const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
-        act_fwd_fast_n<4>(x, act);
+        if (a.preact && a.preact_grad) {
+            float dd[4];
+            act_fwd_grad_fast_n<4>(x, dd, act);
+            Vec4<TC>::st((TC*)a.preact + off, dd);
+        } else {
+            if (a.preact) Vec4<TC>::st((TC*)a.preact + off, x);
+            act_fwd_fast_n<4>(x, act);
+        }
     }
     if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);  // N % 4 == 0 on this path: ld = N
@@ -149,6 +156,11 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
         Vec4<TC>::ld((const TC*)a.residual + off, y);
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] += y[t];
+    }
+    if (EPI == EPI_DMUL) {
+        Vec4<TC>::ld((const TC*)a.dact_aux + off, y);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] *= y[t];
     }
     if (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_ANY) {
         if (a.dact_aux) {
@@ -189,7 +201,7 @@ template <> struct Vec8<bf16_t> {
 template <typename TC, int EPI>
 DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const float* bias8, bool has_pre,
                       const u32x4 pre) {
-    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU);
+    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_DMUL);
     const int64_t off = m * a.ldc + n;
     float y[8];
 #pragma unroll
@@ -199,9 +211,15 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
         for (int t = 0; t < 8; ++t) x[t] += bias8[t];
     }
     if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
-        if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
         const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
-        act_fwd_fast_n<8>(x, act);
+        if (a.preact && a.preact_grad) {
+            float dd[8];
+            act_fwd_grad_fast_n<8>(x, dd, act);
+            Vec8<TC>::st((TC*)a.preact + off, dd);
+        } else {
+            if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
+            act_fwd_fast_n<8>(x, act);
+        }
     }
     if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);
@@ -212,6 +230,12 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
         else Vec8<TC>::ld((const TC*)a.residual + off, y);
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += y[t];
+    }
+    if (EPI == EPI_DMUL) {  // the saved tensor already holds act'(pre): one multiply
+        if (has_pre) Vec8<TC>::unpack(pre, y);
+        else Vec8<TC>::ld((const TC*)a.dact_aux + off, y);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] *= y[t];
     }
     if (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_ANY) {
         if (a.dact_aux) {
@@ -238,7 +262,7 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
                           f32x4 (&acc)[MI][4]) {
     constexpr int LDW = 68;
     constexpr bool BF = sizeof(TC) == 2;
-    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU);
+    constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_DMUL);
     float* t = (float*)smem + wave * 32 * LDW;
     const int64_t ncol = n_base + (lane & 7) * 8;
     // everything the epilogue reads from global memory is requested up front: the wave waits for DRAM once
@@ -750,6 +774,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.M = d.M; a.N = d.N; a.K = d.K;
     a.c_f32 = d.dtype_c == M3AE_F32;
     a.alpha = d.alpha; a.accumulate = d.accumulate; a.bias = d.bias; a.act = d.act; a.preact = d.preact;
+    a.preact_grad = d.preact_grad;
     a.residual = d.residual; a.dact_aux = d.dact_aux; a.dact = d.dact;
     a.rows_epi = (d.N % 8 == 0 && d.c_sm % 8 == 0) ? 1 : 0;
     a.has_drop = d.dropout_p > 0.f;
@@ -759,6 +784,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     if (a.has_drop) return launch_nt_v<EPI_ANY>(a, s);
     if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);
     if (!has_dact && d.act == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_QGELU>(a, s);
+    if (!has_act && has_dact && d.dact == M3AE_ACT_MULAUX) return launch_nt_v<EPI_DMUL>(a, s);
     if (!has_act && d.dact == M3AE_ACT_GELU) return launch_nt_v<EPI_DGELU>(a, s);
     if (!has_act && d.dact == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_DQGELU>(a, s);
     return launch_nt_v<EPI_ANY>(a, s);

@@ -6,7 +6,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libm3ae_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_TANH, ACT_RELU, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
         ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
         ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
         ("dact_aux", vp), ("dact", i32), ("force_generic", i32), ("a_rowsum", vp),
-        ("dropout_p", f32), ("dropout_seed", C.c_uint64),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("preact_grad", i32),
     ]
 
 

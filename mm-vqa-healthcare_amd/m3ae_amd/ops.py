@@ -8,13 +8,17 @@ through `grad_ready_hook`.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, check)
+from ._lib import (ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, check)
 
 grad_ready_hook = None  # callable(param) set by the DDP reducer
+# forward activation GEMMs save act'(pre-activation) for their backward GEMM (A/B knob: M3AE_SAVE_DACT=0 saves the
+# pre-activation and re-evaluates the derivative in the backward epilogue, the first scheme of this repo)
+SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
 PROFILE = None  # when a list: every GEMM / attention launch is bracketed by HIP events on the launch stream
 
 
@@ -81,7 +85,7 @@ def compute_weight(w):
 # ----------------------------------------------------------------------------------------------------------
 def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulate=False, bias=None, act=ACT_NONE,
          preact=None, residual=None, dact_aux=None, dact=ACT_NONE, force_generic=False, batch=(1, 1),
-         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0), a_rowsum=None, dropout=None):
+         a_sb=(0, 0), b_sb=(0, 0), c_sb=(0, 0), a_rowsum=None, dropout=None, preact_grad=False):
     _need_cuda(c)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -101,6 +105,7 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
             assert t.dtype == c.dtype and t.stride(-1) == 1 and t.stride(-2) == c_sm, name
             setattr(d, name, t.data_ptr())
     d.dact = dact
+    d.preact_grad = int(preact_grad)
     d.force_generic = int(force_generic)
     if a_rowsum is not None:
         assert a_rowsum.dtype == torch.float32 and a_rowsum.numel() >= M and batch == (1, 1)
@@ -130,13 +135,15 @@ def _rows(x):
 
 
 def mm_nt(x2, ldx, M, w, bias=None, act=ACT_NONE, residual=None, want_preact=False, out_dtype=None, dact_aux=None,
-          dact=ACT_NONE, force_generic=False, alpha=1.0, dropout=None):
-    """y[M,N] = epi(alpha * x2[M,K] . w[N,K]^T)."""
+          dact=ACT_NONE, force_generic=False, alpha=1.0, dropout=None, preact_grad=False):
+    """y[M,N] = epi(alpha * x2[M,K] . w[N,K]^T).  want_preact + preact_grad: the second output is act'(pre-activation)
+    (consumed by a backward GEMM with dact=ACT_MULAUX) instead of the pre-activation itself."""
     N, K = w.shape
     y = torch.empty((M, N), dtype=out_dtype or x2.dtype, device=x2.device)
     pre = torch.empty_like(y) if want_preact else None
     gemm(x2, ldx, 1, w, 1, w.stride(0), y, N, M, N, K, bias=bias, act=act, preact=pre, residual=residual,
-         dact_aux=dact_aux, dact=dact, force_generic=force_generic, alpha=alpha, dropout=dropout)
+         dact_aux=dact_aux, dact=dact, force_generic=force_generic, alpha=alpha, dropout=dropout,
+         preact_grad=preact_grad and want_preact)
     return y, pre
 
 
@@ -302,7 +309,7 @@ class MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, w1, b1, w2, b2, act):
         x2, M, K, ldx = _rows(x)
-        g, u = mm_nt(x2, ldx, M, compute_weight(w1), bias=b1, act=act, want_preact=True)
+        g, u = mm_nt(x2, ldx, M, compute_weight(w1), bias=b1, act=act, want_preact=True, preact_grad=SAVE_DACT)
         res2 = residual.contiguous().view(M, -1) if residual is not None else None
         y, _ = mm_nt(g, g.stride(0), M, compute_weight(w2), bias=b2, residual=res2)
         ctx.save_for_backward(x2, u, g)
@@ -317,7 +324,7 @@ class MLPFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
         dres = dy if ctx.has_res else None
         mm_wgrad(dy2, g, g.stride(0), w2, b2)
-        du = mm_dgrad(dy2, w2, dact_aux=u, dact=ctx.act)  # dU = (dY W2) * act'(U)
+        du = mm_dgrad(dy2, w2, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ctx.act)  # dU = (dY W2) * act'(U), act'(U) saved by the forward
         mm_wgrad(du, x2, ctx.ldx, w1, b1)
         dx = mm_dgrad(du, w1).view(ctx.x_shape)
         return dx, dres, None, None, None, None, None
@@ -613,7 +620,7 @@ def _ffn_sub_fwd(h2, P, pdrop=0.0):
     """BertIntermediate + BertOutput (bert_model.py:416-442, 500-503); pdrop: hidden dropout on the output dense (:440)."""
     M, D = h2.shape
     dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
-    g, u = mm_nt(h2, D, M, compute_weight(P.w1), bias=_bdata(P.b1), act=ACT_GELU, want_preact=True)
+    g, u = mm_nt(h2, D, M, compute_weight(P.w1), bias=_bdata(P.b1), act=ACT_GELU, want_preact=True, preact_grad=SAVE_DACT)
     s, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), bias=_bdata(P.b2), residual=h2, dropout=dh)
     y, mean, rstd = ln_fwd_raw(s, P.ln)
     return y, (h2, u, g, s, mean, rstd, dh)
@@ -626,7 +633,7 @@ def _ffn_sub_bwd(dy, saved, P):
     else:
         ds = dsd = ln_bwd_raw(dy, s, P.ln, mean, rstd)
     mm_wgrad(dsd, g, g.shape[1], P.w2, P.b2)
-    du = mm_dgrad(dsd, P.w2, dact_aux=u, dact=ACT_GELU)
+    du = mm_dgrad(dsd, P.w2, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ACT_GELU)  # u holds gelu'(pre-activation)
     mm_wgrad(du, h2, h2.shape[1], P.w1, P.b1)
     return mm_dgrad(du, P.w1, residual=ds)
 
@@ -700,7 +707,8 @@ class ClipBlockFn(torch.autograd.Function):
         o, lse = attn_forward(v3[..., :D], v3[..., D:2 * D], v3[..., 2 * D:], P.heads, None)
         xa, _ = mm_nt(o.view(M, D), D, M, compute_weight(P.w_out), bias=_bdata(P.b_out), residual=x2)
         h2, m2, r2 = ln_fwd_raw(xa, P.ln2)
-        g, u = mm_nt(h2, D, M, compute_weight(P.w_fc), bias=_bdata(P.b_fc), act=ACT_QUICKGELU, want_preact=True)
+        g, u = mm_nt(h2, D, M, compute_weight(P.w_fc), bias=_bdata(P.b_fc), act=ACT_QUICKGELU, want_preact=True,
+                     preact_grad=SAVE_DACT)
         y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w_proj), bias=_bdata(P.b_proj), residual=xa)
         ctx.saved = (x2, m1, r1, h1, qkv, o, lse, xa, m2, r2, h2, u, g)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
@@ -715,7 +723,7 @@ class ClipBlockFn(torch.autograd.Function):
         P = ctx.P
         dy2 = dy.contiguous().view(M, D)
         mm_wgrad(dy2, g, g.shape[1], P.w_proj, P.b_proj)
-        du = mm_dgrad(dy2, P.w_proj, dact_aux=u, dact=ACT_QUICKGELU)
+        du = mm_dgrad(dy2, P.w_proj, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ACT_QUICKGELU)
         mm_wgrad(du, h2, D, P.w_fc, P.b_fc)
         dh2 = mm_dgrad(du, P.w_fc)
         dxa = ln_bwd_raw(dh2, xa, P.ln2, m2, r2, dx_add=dy2)  # + residual branch, fused into LN backward
@@ -795,7 +803,7 @@ def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need
 def _t5_ff_fwd(h2, P):
     n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
     M, D = n.shape
-    g, u = mm_nt(n, D, M, compute_weight(P.w1), act=ACT_RELU, want_preact=True)
+    g, u = mm_nt(n, D, M, compute_weight(P.w1), act=ACT_RELU, want_preact=True, preact_grad=SAVE_DACT)
     y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), residual=h2)
     return y, (h2, rstd, n, u, g)
 
@@ -803,7 +811,7 @@ def _t5_ff_fwd(h2, P):
 def _t5_ff_bwd(dy, saved, P):
     h2, rstd, n, u, g = saved
     mm_wgrad(dy, g, g.shape[1], P.w2)
-    du = mm_dgrad(dy, P.w2, dact_aux=u, dact=ACT_RELU)
+    du = mm_dgrad(dy, P.w2, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ACT_RELU)
     mm_wgrad(du, n, n.shape[1], P.w1)
     dn = mm_dgrad(du, P.w1)
     return ln_bwd_raw(dn, h2, P.ln, None, rstd, dx_add=dy, rms=True)

@@ -503,3 +503,29 @@ def test_vocab_projection_padded_mfma_path_for_odd_vocabulary():
     close(x.grad, xr.grad, 3e-2, 2e-2 * xr.grad.abs().max().item(), msg="dx")
     close(head.decoder.weight.grad, w.grad, 3e-2, 2e-2 * w.grad.abs().max().item(), msg="dW")
     close(head.bias.grad, bb.grad, 3e-2, 2e-2 * bb.grad.abs().max().item(), msg="db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1154, 3072, 768), (200, 136, 128), (5000, 1024, 256)])
+def test_gemm_saved_activation_derivative_scheme(dtype, M, N, K):
+    """Forward epilogue with preact_grad: second output = act'(pre-activation); backward epilogue with
+    dact=ACT_MULAUX: dX-GEMM output times that saved derivative.  Against torch autograd, all three activations."""
+    x, w = rnd(M, K, dtype=dtype, seed=95), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=96)
+    b = rnd(N, seed=97)
+    dy = rnd(M, 64, dtype=dtype, seed=98)
+    w2 = rnd(N, 64, dtype=dtype, scale=0.1, seed=99)   # dU = (dY . W2^T) * act'(U)
+    tol = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 2e-2)
+    for act, tact in [(ops.ACT_GELU, torch.nn.functional.gelu), (ops.ACT_QUICKGELU, lambda t: t * torch.sigmoid(1.702 * t)),
+                      (ops.ACT_RELU, torch.relu)]:
+        y, dsaved = ops.mm_nt(x, K, M, w, bias=b, act=act, want_preact=True, preact_grad=True)
+        u = (x.float() @ w.float().t() + b).requires_grad_(True)
+        yr = tact(u)
+        (dref,) = torch.autograd.grad(yr.sum(), u)
+        close(y, yr, *tol, msg=f"y act={act}")
+        if act == ops.ACT_RELU:   # derivative at exactly 0 is a convention; compare away from the kink
+            far = u.detach().abs() > 1e-3
+            close(dsaved[far], dref[far], *tol, msg="relu'")
+        else:
+            close(dsaved, dref, *tol, msg=f"act' act={act}")
+        du, _ = ops.mm_nt(dy, 64, M, w2, dact_aux=dsaved, dact=ops.ACT_MULAUX)
+        close(du, (dy.float() @ w2.float().t()) * dsaved.float(), *tol, msg=f"mulaux act={act}")
