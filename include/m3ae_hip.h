@@ -212,8 +212,8 @@ int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void* d_in, int
                           void* stream);
 
 /* tuning knobs for A/B measurements (process-global, not part of the data path contract).
- * key 0: NT GEMM tile variant (-1 = auto by shape, 0..7 = fixed: see gemm_mfma.hip launch_nt_v; 7 = ping-pong kernel);
- * key 1: TN (wgrad) variant (-1 = auto by shape, 0..4 = fixed tilings of gemm_tn_bf16_kernel, 5 = ping-pong kernel). */
+ * key 0: NT GEMM kernel (-1 = auto by shape; 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong);
+ * key 1: TN (wgrad) kernel (-1 = auto by shape; 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong). */
 int m3ae_set_tuning(int key, int value);
 
 /* self-test of hardware idioms the kernels rely on (MFMA fragment maps, ds_read_b64_tr_b16, accumulator-as-

@@ -737,14 +737,12 @@ static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
 }
 
 // variants (m3ae_set_tuning key 0):
-//   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU
-//   1: 256x128 tile, BK 64, 3 stages, 8 waves x (64x64)   -- 144 KiB LDS, 1 workgroup / CU, counted vmcnt
-//   2: 256x128 tile, BK 32, 2 stages, 4 waves x (128x64)  -- 48 KiB LDS, 2 workgroups / CU, 25 % less L2->LDS traffic
-//      and LDS-read traffic per FLOP (12 fragment reads per 32 MFMAs)
-//   3: 256x256 tile, BK 32, 4 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU: half the L1->LDS bytes/FLOP
-//   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU
-//   6: 256x128 tile, BK 32, 3 stages, 4 waves x (128x64)  -- 72 KiB LDS, 2 workgroups / CU
+//   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU (small / few-tile shapes)
+//   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU (the ping-pong kernel's
+//      bit-exact reference in tools/gemm_race.py)
 //   7: 256x256 tile, 32-deep chunks in a 4-slot ring, 8 waves in two staggered rows (ping-pong, gemm_nt_pp_kernel)
+// Tilings tried and dropped (measured slower on every shape of the path, r01 logs): 256x128 with BK 64 / 3 stages,
+// 256x128 with BK 32 / 2 and 3 stages, 256x256 with BK 32 / 4 stages (single barrier), 128x128 with BK 32.
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
@@ -757,12 +755,7 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
     if (g_nt_variant == 7 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);  // ping-pong 8-phase
-    if (g_nt_variant == 5) return launch_nt_t<128, 128, 32, 2, 64, EPI>(a, s);  // 34 KiB LDS: 4 workgroups / CU
-    if (g_nt_variant == 6 && a.M > 128) return launch_nt_t<256, 128, 32, 3, 128, EPI>(a, s);  // 72 KiB LDS: 2 workgroups / CU
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
-    if (g_nt_variant == 3 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 32, 4, 128, EPI>(a, s);
-    if (g_nt_variant == 2 && a.M > 128) return launch_nt_t<256, 128, 32, 2, 128, EPI>(a, s);
-    if (g_nt_variant == 1 && a.M > 128) return launch_nt_t<256, 128, 64, 3, 64, EPI>(a, s);
     return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
 }
 
@@ -1004,10 +997,7 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
         if (pp_ok && (d.K >= 65536 || (d.K >= 32768 && d.M * d.N >= 768 * 3072))) return launch_tn_pp(a, d, s);
         return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);
     }
-    if (g_tn_variant == 1 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096) return launch_tn_t<256, 256, 128, 64, 2>(a, d, s);
     if (g_tn_variant == 2) return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);  // 32 KiB LDS: 3 workgroups / CU
-    if (g_tn_variant == 3) return launch_tn_t<128, 128, 64, 32, 4>(a, d, s);  // 4-stage ring of 32-row steps, counted vmcnt
-    if (g_tn_variant == 4) return launch_tn_t<128, 128, 64, 64, 3>(a, d, s);  // 3-stage ring, 96 KiB, 1 workgroup / CU
     return launch_tn_t<128, 128, 64, 64, 2>(a, d, s);
 }
 

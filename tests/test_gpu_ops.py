@@ -52,7 +52,7 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
         assert ops.last_gemm_path() == expect
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 4, 7])
 def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
     from m3ae_amd import _lib

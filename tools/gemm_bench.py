@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from m3ae_amd import _lib, ops  # noqa: E402
 
 B = int(os.environ.get("B", 64))
-VARS = tuple(int(v) for v in os.environ.get('VARS', '0,4,6').split(','))
+VARS = tuple(int(v) for v in os.environ.get('VARS', '0,4,7').split(','))
 M = B * 577
 NT_SHAPES = [(M, 3072, 768)] if os.environ.get('TN_ONLY') else [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768), (B * 32, 768, 3072), (B * 32, 2304, 768),
              (4096, 4096, 4096), (8192, 8192, 8192)]
@@ -46,7 +46,7 @@ def main():
         print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in VARS), flush=True)
     # epilogue-heavy forms on the dominant shapes
     m = M
-    for vv in tuple(int(v) for v in os.environ.get('EVARS', '0,2,3,4,6').split(',')):
+    for vv in tuple(int(v) for v in os.environ.get('EVARS', '0,4,7').split(',')):
       L.m3ae_set_tuning(0, vv)
       print("variant", vv)
       for (n, k, kind) in [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (768, 768, "bias+res"), (768, 3072, "bias+res")]:
