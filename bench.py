@@ -113,9 +113,9 @@ def main():
         model = M3AETransformerSS(cfg)
     synth.fill_deterministic(model)  # random-init weights of the named architecture (no checkpoints offline)
     model.finalize(dev, torch.bfloat16)
-    # the reference fine-tunes in train() mode with drop_rate = 0.1 (m3ae/config.py:74): dropout is part of the step.
-    # The T5 generative head's own dropout sites are not built yet, so that mode runs eval-mode semantics.
-    model.train(args.head == "cls" and not args.no_dropout)
+    # the reference trains in train() mode with drop_rate = 0.1 (m3ae/config.py:74; T5Config.dropout_rate 0.1): dropout
+    # is part of the step in every mode
+    model.train(not args.no_dropout)
     store = model.store
     reducer = FlatGradReducer(store).attach()
 
@@ -284,7 +284,7 @@ def main():
                              "teacher-forced decoder / tied LM head, top-4 encoder + top-4 decoder attention blocks "
                              "trainable (main_t5_m3ae.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "dropout": ("p=0.1 in RoBERTa + fusion layers (train mode, as the reference)" if model.training
+                       "dropout": ("p=0.1 at every dropout site of the model (train mode, as the reference)" if model.training
                                    else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)"},
             "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1) if args.head == "cls" else None,
             "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)

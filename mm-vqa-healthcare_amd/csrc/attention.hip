@@ -943,13 +943,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     }
 }
 
-// coop kernels: mask / bias / causal as below plus the dropout instances (BERT layers only: no bias, not causal)
+// coop kernels: mask / bias / causal as below plus the dropout instances: BERT layers (optional key mask) and T5 layers
+// (relative-position bias, optionally causal)
 #define ATTN_DISPATCH_COOP(rc, KERNEL, grid, s, a, ...)                                                                  \
     do {                                                                                                                 \
         const int f = (a.key_mask ? 1 : 0) | (a.pos_bias ? 2 : 0) | (a.causal ? 4 : 0);                                  \
         if (a.has_drop) {                                                                                                \
             if (f == 0) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, false, true>), grid, dim3(256), 0, s, a);   \
             else if (f == 1) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, false, true>), grid, dim3(256), 0, s, a); \
+            else if (f == 2) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, false, true>), grid, dim3(256), 0, s, a); \
+            else if (f == 6) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, true, true>), grid, dim3(256), 0, s, a);  \
             else rc = M3AE_ERR_UNSUPPORTED;                                                                              \
             break;                                                                                                       \
         }                                                                                                                \

@@ -113,9 +113,10 @@ def _attn_params(att, ln, cross):
 
 
 class T5Block(nn.Module):
-    def __init__(self, d_model, heads, d_kv, d_ff, has_bias, is_decoder):
+    def __init__(self, d_model, heads, d_kv, d_ff, has_bias, is_decoder, dropout_rate=0.1):
         super().__init__()
         self.is_decoder = is_decoder
+        self.dropout_rate = dropout_rate  # T5Config.dropout_rate (0.1 for t5-small / t5-base)
         layers = [_SelfAttnLayer(d_model, heads, d_kv, has_bias, is_decoder)]
         if is_decoder:
             layers.append(_CrossAttnLayer(d_model, heads, d_kv))
@@ -137,6 +138,7 @@ class T5Block(nn.Module):
 
     def forward(self, h, pos_bias, enc=None):
         P = self.params()
+        P.pdrop = self.dropout_rate if self.training else 0.0
         if self.is_decoder:
             return ops.T5DecBlockFn.apply(h, enc, pos_bias, P, *self._anchors)
         return ops.T5EncBlockFn.apply(h, pos_bias, P, *self._anchors)
@@ -152,19 +154,24 @@ class T5Block(nn.Module):
 
 
 class T5Stack(nn.Module):
-    def __init__(self, n_layers, d_model, heads, d_kv, d_ff, is_decoder):
+    def __init__(self, n_layers, d_model, heads, d_kv, d_ff, is_decoder, dropout_rate=0.1):
         super().__init__()
         self.is_decoder = is_decoder
-        self.block = nn.ModuleList([T5Block(d_model, heads, d_kv, d_ff, i == 0, is_decoder) for i in range(n_layers)])
+        self.dropout_rate = dropout_rate
+        self.block = nn.ModuleList([T5Block(d_model, heads, d_kv, d_ff, i == 0, is_decoder, dropout_rate)
+                                    for i in range(n_layers)])
         self.final_layer_norm = T5LayerNorm(d_model)
 
     def forward(self, h, enc=None):
+        """HF T5Stack.forward: dropout(inputs_embeds) -> blocks -> dropout(final_layer_norm(h)); every dropout site is
+        active in train() mode (frozen blocks included, as in the reference: freezing only clears requires_grad)."""
         L = h.shape[1]
+        h = ops.dropout(h, self.dropout_rate, self.training)
         bias = self.block[0].layer[0].SelfAttention.position_bias(L, L)
         for blk in self.block:
             h = blk(h, bias, enc)
         ln = self.final_layer_norm
-        return ops.layer_norm(h, ln.weight, None, ln.eps, rms=True)
+        return ops.dropout(ops.layer_norm(h, ln.weight, None, ln.eps, rms=True), self.dropout_rate, self.training)
 
     def weight_units(self):
         u = []
@@ -184,8 +191,9 @@ class T5ForConditionalGeneration(nn.Module):
                          num_heads=dims["num_heads"], pad_token_id=0, decoder_start_token_id=0, eos_token_id=1)
         d = dims["d_model"]
         self.shared = nn.Embedding(vocab_size, d)
-        self.encoder = T5Stack(dims["num_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], False)
-        self.decoder = T5Stack(dims["num_decoder_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], True)
+        dr = dims.get("dropout_rate", 0.1)
+        self.encoder = T5Stack(dims["num_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], False, dr)
+        self.decoder = T5Stack(dims["num_decoder_layers"], d, dims["num_heads"], dims["d_kv"], dims["d_ff"], True, dr)
 
     def weight_units(self):
         return [self.shared.weight] + self.encoder.weight_units() + self.decoder.weight_units()

@@ -147,7 +147,7 @@ def mm_nt(x2, ldx, M, w, bias=None, act=ACT_NONE, residual=None, want_preact=Fal
     return y, pre
 
 
-def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None, alpha=1.0):
+def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None, alpha=1.0, dropout=None):
     """dx[M,K] = dy[M,N] . W[N,K]  (bf16: NT against the transposed shadow; fp32: strided generic)."""
     M, N = dy.shape
     wt = getattr(w_param, "m3ae_t", None)
@@ -155,13 +155,13 @@ def mm_dgrad(dy, w_param, dact_aux=None, dact=ACT_NONE, residual=None, alpha=1.0
         K = wt.shape[0]
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
         gemm(dy, dy.stride(0), 1, wt, 1, wt.stride(0), dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual,
-             alpha=alpha)
+             alpha=alpha, dropout=dropout)
     else:
         w = compute_weight(w_param)
         K = w.shape[1]
         dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
         gemm(dy, dy.stride(0), 1, w, w.stride(0), 1, dx, K, M, K, N, dact_aux=dact_aux, dact=dact, residual=residual,
-             alpha=alpha)
+             alpha=alpha, dropout=dropout)
     return dx
 
 
@@ -462,7 +462,7 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     o = torch.empty((B, Lq, D), dtype=q.dtype, device=q.device)
     lse_stride = (Lq + 31) // 32 * 32
-    lse = torch.empty((B, heads, lse_stride), dtype=torch.float32, device=q.device)
+    lse = torch.zeros((B, heads, lse_stride), dtype=torch.float32, device=q.device)  # padding rows stay finite
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
     if dropout is not None and dropout[0] > 0:
         d.dropout_p, d.dropout_seed = dropout
@@ -482,7 +482,7 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     assert do.stride() == o.stride() and dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse.shape[-1], _dt(q))
-    delta = torch.empty_like(lse)
+    delta = torch.zeros_like(lse)  # rows Lq .. lse_stride-1 are padding: they must stay finite (0 * NaN in the dK/dV tile)
     d.d_o, d.dq, d.dk, d.dv, d.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
     if dropout is not None and dropout[0] > 0:
@@ -744,7 +744,21 @@ class ClipBlockFn(torch.autograd.Function):
 # T5 pre-norm blocks (HF T5Block restated; m3ae_t5_mm_encoder_input.py:202,244): RMSNorm, no linear biases, no
 # 1/sqrt(d) scaling, additive relative-position bias, ReLU FFN.  One autograd node per block.
 # ----------------------------------------------------------------------------------------------------------
-def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal):
+def _drop_raw(x2, drop):
+    """dropout of a 2-D activation with an explicit (p, seed): the gradient entering a dropped sub-layer output."""
+    if drop is None:
+        return x2
+    x2 = x2.contiguous()
+    out = torch.empty_like(x2)
+    check(_lib.lib().m3ae_dropout(_p(x2), _p(out), None, x2.shape[0], x2.shape[1], drop[0], drop[1], _dt(x2), _stream()),
+          "m3ae_dropout")
+    return out
+
+
+def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal, pdrop=0.0):
+    # HF T5 (third party, transformers 4.6.0): attention-weight dropout inside T5Attention and `hidden + dropout(attn)`
+    da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
+    dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
     D = n.shape[1]
     inner = P.w_o.shape[1]
@@ -752,26 +766,27 @@ def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal):
         qkv, _ = mm_nt(n, D, B * L, compute_weight(P.w_qkv))
         v3 = qkv.view(B, L, 3 * inner)
         o, lse = attn_forward(v3[..., :inner], v3[..., inner:2 * inner], v3[..., 2 * inner:], P.heads, None, bias,
-                              scale=1.0, causal=causal)
+                              scale=1.0, causal=causal, dropout=da)
         proj = (qkv,)
     else:
         q, _ = mm_nt(n, D, B * L, compute_weight(P.w_q))
         kv, _ = mm_nt(src2, src2.shape[1], B * Ls, compute_weight(P.w_kv))
         kv3 = kv.view(B, Ls, 2 * inner)
         o, lse = attn_forward(q.view(B, L, inner), kv3[..., :inner], kv3[..., inner:], P.heads, None, bias, scale=1.0,
-                              causal=causal)
+                              causal=causal, dropout=da)
         proj = (q, kv)
-    y, _ = mm_nt(o.view(B * L, inner), inner, B * L, compute_weight(P.w_o), residual=h2)
-    return y, (h2, rstd, n, proj, o, lse, src2)
+    y, _ = mm_nt(o.view(B * L, inner), inner, B * L, compute_weight(P.w_o), residual=h2, dropout=dh)
+    return y, (h2, rstd, n, proj, o, lse, src2, da, dh)
 
 
 def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need_dsrc=True):
-    h2, rstd, n, proj, o, lse, src2 = saved
+    h2, rstd, n, proj, o, lse, src2, da, dh_drop = saved
     need_dh = need_dh or P.ln.weight.requires_grad  # the RMSNorm scale gradient comes out of the same kernel
     D = n.shape[1]
     inner = P.w_o.shape[1]
-    mm_wgrad(dy, o.view(B * L, inner), inner, P.w_o)
-    dctx = mm_dgrad(dy, P.w_o).view(B, L, inner)
+    dyd = _drop_raw(dy, dh_drop)  # gradient of the (dropped) sub-layer output; the residual branch keeps dy itself
+    mm_wgrad(dyd, o.view(B * L, inner), inner, P.w_o)
+    dctx = mm_dgrad(dyd, P.w_o).view(B, L, inner)
     dsrc = None
     if src2 is None:
         (qkv,) = proj
@@ -780,7 +795,7 @@ def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need
         d3 = dqkv.view(B, L, 3 * inner)
         attn_backward(v3[..., :inner], v3[..., inner:2 * inner], v3[..., 2 * inner:], o, lse, dctx, d3[..., :inner],
                       d3[..., inner:2 * inner], d3[..., 2 * inner:], P.heads, None, bias, scale=1.0, causal=causal,
-                      d_pos_bias=dbias)
+                      d_pos_bias=dbias, dropout=da)
         mm_wgrad(dqkv, n, D, P.w_qkv)
         dn = mm_dgrad(dqkv, P.w_qkv) if need_dh else None
     else:
@@ -791,7 +806,7 @@ def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need
         dkv3 = dkv.view(B, Ls, 2 * inner)
         attn_backward(q.view(B, L, inner), kv3[..., :inner], kv3[..., inner:], o, lse, dctx, dq.view(B, L, inner),
                       dkv3[..., :inner], dkv3[..., inner:], P.heads, None, bias, scale=1.0, causal=causal,
-                      d_pos_bias=dbias)
+                      d_pos_bias=dbias, dropout=da)
         mm_wgrad(dq, n, D, P.w_q)
         mm_wgrad(dkv, src2, src2.shape[1], P.w_kv)
         dn = mm_dgrad(dq, P.w_q) if need_dh else None
@@ -800,18 +815,22 @@ def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need
     return dh, dsrc
 
 
-def _t5_ff_fwd(h2, P):
+def _t5_ff_fwd(h2, P, pdrop=0.0):
+    # HF T5DenseReluDense: wo(dropout(relu(wi(x)))); T5LayerFF: hidden + dropout(ff)
+    d1 = (pdrop, next_dropout_seed()) if pdrop > 0 else None
+    d2 = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
     M, D = n.shape
-    g, u = mm_nt(n, D, M, compute_weight(P.w1), act=ACT_RELU, want_preact=True, preact_grad=SAVE_DACT)
-    y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), residual=h2)
-    return y, (h2, rstd, n, u, g)
+    g, u = mm_nt(n, D, M, compute_weight(P.w1), act=ACT_RELU, want_preact=True, preact_grad=SAVE_DACT, dropout=d1)
+    y, _ = mm_nt(g, g.shape[1], M, compute_weight(P.w2), residual=h2, dropout=d2)
+    return y, (h2, rstd, n, u, g, d1, d2)
 
 
 def _t5_ff_bwd(dy, saved, P):
-    h2, rstd, n, u, g = saved
-    mm_wgrad(dy, g, g.shape[1], P.w2)
-    du = mm_dgrad(dy, P.w2, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ACT_RELU)
+    h2, rstd, n, u, g, d1, d2 = saved
+    dyd = _drop_raw(dy, d2)
+    mm_wgrad(dyd, g, g.shape[1], P.w2)                     # g is the dropped activation the forward multiplied by W2
+    du = mm_dgrad(dyd, P.w2, dact_aux=u, dact=ACT_MULAUX if SAVE_DACT else ACT_RELU, dropout=d1)
     mm_wgrad(du, n, n.shape[1], P.w1)
     dn = mm_dgrad(du, P.w1)
     return ln_bwd_raw(dn, h2, P.ln, None, rstd, dx_add=dy, rms=True)
@@ -823,8 +842,9 @@ class T5EncBlockFn(torch.autograd.Function):
         B, L, D = h.shape
         h2 = h.contiguous().view(B * L, D)
         bias = pos_bias.detach() if pos_bias is not None else None
-        a, s1 = _t5_attn_fwd(h2, B, L, None, L, P.attn, bias, False)
-        y, s2 = _t5_ff_fwd(a, P.ffn)
+        pd = getattr(P, "pdrop", 0.0)
+        a, s1 = _t5_attn_fwd(h2, B, L, None, L, P.attn, bias, False, pd)
+        y, s2 = _t5_ff_fwd(a, P.ffn, pd)
         ctx.saved = (s1, s2, bias)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, D), len(anchors)
         ctx.need_h = h.requires_grad
@@ -850,9 +870,10 @@ class T5DecBlockFn(torch.autograd.Function):
         h2 = h.contiguous().view(B * T, D)
         enc2 = enc.contiguous().view(B * Ls, enc.shape[2])
         bias = pos_bias.detach() if pos_bias is not None else None
-        a, s1 = _t5_attn_fwd(h2, B, T, None, T, P.attn, bias, True)
-        c, s2 = _t5_attn_fwd(a, B, T, enc2, Ls, P.cross, None, False)
-        y, s3 = _t5_ff_fwd(c, P.ffn)
+        pd = getattr(P, "pdrop", 0.0)
+        a, s1 = _t5_attn_fwd(h2, B, T, None, T, P.attn, bias, True, pd)
+        c, s2 = _t5_attn_fwd(a, B, T, enc2, Ls, P.cross, None, False, pd)
+        y, s3 = _t5_ff_fwd(c, P.ffn, pd)
         ctx.saved = (s1, s2, s3, bias)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, T, Ls, D), len(anchors)
         ctx.need_h, ctx.need_enc = h.requires_grad, enc.requires_grad

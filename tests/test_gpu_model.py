@@ -482,3 +482,31 @@ def test_full_size_bench_batch_properties():
     rel = ((g2 - 2.0 * g1).double().norm() / (2.0 * g1).double().norm()).item()
     assert rel < 1e-3, rel
     assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+
+
+def test_t5_head_training_mode_dropout_is_seeded_and_active():
+    """configs[2] in train() mode: every HF-T5 dropout site (embeddings, attention weights, sub-layer outputs, inside the
+    feed-forward, final norm) plus the frozen M3AE's own: reproducible from the seed, different across seeds / from eval."""
+    from m3ae_amd import ops
+    m = _build_t5("bf16", torch.bfloat16)
+    g = load_golden("tiny_t5.npz")
+    b = to_dev(tiny_batch())
+    b["t5_labels"] = torch.from_numpy(g["labels"]).cuda()
+
+    def step(seed, train=True):
+        m.train(train)
+        m.store.zero_grad()
+        ops.set_dropout_seed(seed)
+        loss = m.training_step(b)["loss"]
+        loss.backward()
+        return loss.item(), m.store.grad.clone()
+
+    l1, g1 = step(21)
+    l2, g2 = step(21)
+    l3, g3 = step(22)
+    le, ge = step(21, train=False)
+    assert np.isfinite(l1) and torch.isfinite(g1).all()
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and (g1 - g2).double().norm().item() <= 1e-5 * g1.double().norm().item()
+    assert abs(l1 - l3) > 1e-6 * abs(l1) and (g1 - g3).double().norm().item() > 1e-3 * g1.double().norm().item()
+    assert abs(l1 - le) > 1e-6 * abs(le) and abs(l1 - le) < 0.2 * abs(le)
+    assert abs(le - float(g["loss"])) < 3e-3 * float(g["loss"])   # eval mode is still the reference fixture

@@ -529,3 +529,53 @@ def test_gemm_saved_activation_derivative_scheme(dtype, M, N, K):
             close(dsaved, dref, *tol, msg=f"act' act={act}")
         du, _ = ops.mm_nt(dy, 64, M, w2, dact_aux=dsaved, dact=ops.ACT_MULAUX)
         close(du, (dy.float() @ w2.float().t()) * dsaved.float(), *tol, msg=f"mulaux act={act}")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_dropout_with_position_bias_and_causal(causal):
+    """T5 attention in train mode: relative-position bias (+ causal in the decoder) with attention-weight dropout,
+    forward / backward incl. the bias gradient, against torch with the library's exported mask."""
+    B, H, L, dh, p, seed = 2, 4, 70, 64, 0.1, 0xBEEF01
+    D = H * dh
+    dt = torch.bfloat16
+    q, k, v = (rnd(B, L, D, dtype=dt, seed=s_).requires_grad_(True) for s_ in (101, 102, 103))
+    bias = (0.5 * rnd(H, L, L, seed=104)).contiguous()
+    keep = ops.dropout_keep_mask(B * H * L, L, p, seed).float().view(B, H, L, L)
+    o, lse = ops.attn_forward(q, k, v, H, None, bias, scale=1.0, causal=causal, dropout=(p, seed))
+    do = rnd(B, L, D, dtype=dt, seed=105)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dbias = torch.zeros_like(bias)
+    ops.attn_backward(q, k, v, o, lse, do, dq, dk, dv, H, None, bias, scale=1.0, causal=causal, d_pos_bias=dbias,
+                      dropout=(p, seed))
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    br = bias.clone().requires_grad_(True)
+    sh = lambda t: t.view(B, L, H, dh).permute(0, 2, 1, 3)
+    s = sh(qr) @ sh(kr).transpose(-1, -2) + br[None]
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool, device=dev())), float("-inf"))
+    pr = torch.softmax(s, dim=-1) * keep / (1 - p)
+    oref = (pr @ sh(vr)).permute(0, 2, 1, 3).reshape(B, L, D)
+    oref.backward(do.float())
+    close(o, oref, 2e-2, 2e-2, msg="o")
+    for a, r, n in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+        close(a, r, 2e-2, 2e-2 * r.abs().max().item(), msg=n)   # unscaled scores (T5): gradients of magnitude ~20
+    close(dbias, br.grad, 3e-2, 3e-2 * br.grad.abs().max().item(), msg="d_pos_bias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_dropout_after_activation_and_in_dgrad(dtype):
+    """T5DenseReluDense in train mode: wi GEMM with ReLU + saved derivative + dropout AFTER the activation; the matching
+    dgrad GEMM multiplies by the saved derivative and re-applies the same mask."""
+    M, N, K, p, seed = 1200, 512, 256, 0.1, 0x77AA
+    x, w = rnd(M, K, dtype=dtype, seed=110), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=111)
+    y, d = ops.mm_nt(x, K, M, w, act=ops.ACT_RELU, want_preact=True, preact_grad=True, dropout=(p, seed))
+    mk = ops.dropout_keep_mask(M, N, p, seed).float()
+    u = x.float() @ w.float().t()
+    tol = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 2e-2)
+    close(y, torch.relu(u) * mk / (1 - p), *tol, msg="relu + dropout")
+    far = u.abs() > 1e-3
+    close(d[far], (u > 0).float()[far], *tol, msg="saved derivative is NOT dropped")
+    dy = rnd(M, 64, dtype=dtype, seed=112)
+    w2 = rnd(N, 64, dtype=dtype, scale=0.1, seed=113)
+    du, _ = ops.mm_nt(dy, 64, M, w2, dact_aux=d, dact=ops.ACT_MULAUX, dropout=(p, seed))
+    close(du, (dy.float() @ w2.float().t()) * d.float() * mk / (1 - p), *tol, msg="dgrad: derivative x mask")
