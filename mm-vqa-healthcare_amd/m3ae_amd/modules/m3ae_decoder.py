@@ -17,7 +17,7 @@ The reference's arithmetic is kept as it is, quirks included (each is pinned by 
 
 Arithmetic: the head has 8 heads of 96 channels (768 / 8); the MFMA attention kernels are specialised for 64-wide heads,
 so the head runs in fp32 on the library's generic kernels (fp32 master weights, materialised-softmax attention) in
-both modes; the frozen M3AE below it runs in the configured mode (bf16 MFMA in perf mode).  T <= 12 tokens against
+both modes (train() mode applies the reference's dropout sites with the library's counter-hash masks); the frozen M3AE below it runs in the configured mode (bf16 MFMA in perf mode).  T <= 12 tokens against
 2 (CLS) or 2 + 577 + 32 encoder tokens: the head is < 3 % of the step's FLOPs except for the vocabulary projection.
 Tokenisation happens outside (`batch["decoder_tokens"]`: int64 [B, T] = [CLS] answer [SEP] [PAD]...) or through a
 `tokenizer` callable; string metrics (ROUGE / BLEU / exact match) stay out of scope.
@@ -66,20 +66,32 @@ class DecoderLayer(nn.Module):
 
     def forward(self, t, enc, key_mask):
         D, H = self.mha1.embed_dim, self.mha1.num_heads
+        p = self.p_drop if self.training else 0.0   # MultiheadAttention(dropout=p) on the weights + dropout1..3 (:43-53)
+        att = (lambda: (p, ops.next_dropout_seed())) if p > 0 else (lambda: None)
         # masked (causal + key padding) self-attention on the pre-normed input; residual = the un-normed input
         xn = self._ln(self.pre_norm, t)
         qkv = ops.linear(xn, self.mha1.in_proj_weight, self.mha1.in_proj_bias)
-        ctx = ops.self_attention(qkv, key_mask, H, causal=True)
-        x = ops.linear(ctx, self.mha1.out_proj.weight, self.mha1.out_proj.bias, residual=t)
+        ctx = ops.self_attention(qkv, key_mask, H, dropout=att(), causal=True)
+        if p > 0:
+            x = ops.dropout(ops.linear(ctx, self.mha1.out_proj.weight, self.mha1.out_proj.bias), p) + t
+        else:
+            x = ops.linear(ctx, self.mha1.out_proj.weight, self.mha1.out_proj.bias, residual=t)
         # cross-attention to the multimodal features (no mask: the reference's enc_pad_mask is all False, :71-76)
         xn = self._ln(self.layernorm1, x)
         q = ops.linear(xn, self.mha2.in_proj_weight, self.mha2.in_proj_bias)[..., :D]
         kv = ops.linear(enc, self.mha2.in_proj_weight, self.mha2.in_proj_bias)[..., D:]
-        ctx = ops.cross_attention(q, kv, None, H)
-        x = ops.linear(ctx, self.mha2.out_proj.weight, self.mha2.out_proj.bias, residual=x)
+        ctx = ops.cross_attention(q, kv, None, H, att())
+        if p > 0:
+            x = ops.dropout(ops.linear(ctx, self.mha2.out_proj.weight, self.mha2.out_proj.bias), p) + x
+        else:
+            x = ops.linear(ctx, self.mha2.out_proj.weight, self.mha2.out_proj.bias, residual=x)
         xn = self._ln(self.layernorm2, x)
-        x = ops.mlp(xn, self.ffn[0].weight, self.ffn[0].bias, self.ffn[2].weight, self.ffn[2].bias, ops.ACT_RELU,
-                    residual=x)
+        if p > 0:
+            x = ops.dropout(ops.mlp(xn, self.ffn[0].weight, self.ffn[0].bias, self.ffn[2].weight, self.ffn[2].bias,
+                                    ops.ACT_RELU), p) + x
+        else:
+            x = ops.mlp(xn, self.ffn[0].weight, self.ffn[0].bias, self.ffn[2].weight, self.ffn[2].bias, ops.ACT_RELU,
+                        residual=x)
         return self._ln(self.layernorm3, x)
 
 
@@ -137,6 +149,7 @@ class Decoder(nn.Module):
         self.target_embedding = nn.Embedding(target_vocab_size, d_model)
         self.positional_encoding = PositionalEncoding(d_model)
         self.final_linear = nn.Linear(d_model, target_vocab_size)
+        self.p_drop = dropout   # nn.Dropout on the (doubled) embedding (:128)
 
     def weight_units(self):
         return []  # the head runs in fp32 on the master weights: no bf16 transposed copies
@@ -147,7 +160,7 @@ class Decoder(nn.Module):
         D = self.target_embedding.weight.shape[1]
         pe_rows = self.positional_encoding.pe[0, :T].to(torch.float32).repeat(B, 1).contiguous()
         t = _DecoderEmbedFn.apply(padded_targets.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows)
-        t = t.view(B, T, D)
+        t = ops.dropout(t.view(B, T, D), self.p_drop, self.training)
         key_mask = None
         if padding_mask is not None:
             key_mask = torch.where(padding_mask, 0.0, NEG).to(torch.float32).contiguous()

@@ -510,3 +510,32 @@ def test_t5_head_training_mode_dropout_is_seeded_and_active():
     assert abs(l1 - l3) > 1e-6 * abs(l1) and (g1 - g3).double().norm().item() > 1e-3 * g1.double().norm().item()
     assert abs(l1 - le) > 1e-6 * abs(le) and abs(l1 - le) < 0.2 * abs(le)
     assert abs(le - float(g["loss"])) < 3e-3 * float(g["loss"])   # eval mode is still the reference fixture
+
+
+def test_decoder_head_training_mode_dropout():
+    """DecoderModel in train() mode: embedding / attention-weight / dropout1..3 sites active and seeded."""
+    from m3ae_amd import ops
+    from m3ae_amd.modules import DecoderModel
+    g = load_golden("tiny_decoder.npz")
+    m = DecoderModel(_decoder_cfg("bf16"), vocab_size=1200)
+    synth.fill_deterministic(m)
+    m.finalize("cuda", torch.bfloat16)
+    b = to_dev(synth.synthetic_batch(2, text_len=32, image_size=64, vocab_size=1000, rank=0))
+    b["decoder_tokens"] = torch.from_numpy(g["tokens"]).cuda()
+
+    def step(seed, train=True):
+        m.train(train)
+        m.store.zero_grad()
+        ops.set_dropout_seed(seed)
+        loss = m.training_step(b)["loss"]
+        loss.backward()
+        return loss.item(), m.store.grad.clone()
+
+    l1, g1 = step(31)
+    l2, g2 = step(31)
+    l3, _ = step(32)
+    le, _ = step(31, train=False)
+    assert np.isfinite(l1) and torch.isfinite(g1).all()
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and (g1 - g2).double().norm().item() <= 1e-5 * g1.double().norm().item()
+    assert abs(l1 - l3) > 1e-7 * abs(l1) and abs(l1 - le) > 1e-7 * abs(le)
+    assert abs(le - float(g["loss"])) < 2e-3 * float(g["loss"])
