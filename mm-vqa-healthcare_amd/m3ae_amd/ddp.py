@@ -8,7 +8,11 @@ amortise launch + ring latency.  The wgrad kernels accumulate straight into the 
 finished parameter through `ops.grad_ready_hook`; when the last parameter of a bucket reports, its all-reduce is
 launched asynchronously (torch.distributed orders it after the producing kernels and runs it on RCCL's own stream),
 overlapping the rest of backward.  `finish()` launches whatever is left (parameters whose gradient flows through
-autograd glue never report) and waits.  Averaging (1 / world_size) is folded into the fused AdamW kernel's
+autograd glue never report) and waits.  A parameter can receive SEVERAL in-place contributions per step (the three
+`infer` passes of a pre-training step, an in-projection used for queries and for keys/values): the reducer LEARNS, on its
+first step, how many reports each parameter makes (no early launches on that step) and afterwards launches a bucket only
+when every parameter in it has reported that many times; a report that arrives after its bucket was launched is an
+error (`relearn()`), never a silently half-reduced gradient.  Averaging (1 / world_size) is folded into the fused AdamW kernel's
 `grad_scale`, not applied to the buffer.  The 6 tensors that never receive a gradient are not in the
 buffer at all -- no `find_unused_parameters` pass.
 """
@@ -44,20 +48,58 @@ class FlatGradReducer:
                 bi += 1
             self.bucket_of[id(p)] = bi
             self.pending0[bi] += 1
+        self.expected = None   # reports per parameter per step, learned on the first step
+        self.late = None
+        self.glue = set()      # parameters that (also) receive a gradient through autograd's AccumulateGrad
+        self._params = [p for _, p in params]
+        self._hooks = []
+        self.reset()
+
+    def relearn(self):
+        """Forget the learned report counts (the set of objectives / the graph changed)."""
+        self.expected = None
         self.reset()
 
     def reset(self):
-        self.pending = list(self.pending0)
-        self.seen = set()
+        self.count = {}
+        if self.expected is None:
+            self.pending = [-1] * self.nb          # learning step: nothing launches before finish()
+        else:
+            self.pending = [0] * self.nb
+            for pid, bi in self.bucket_of.items():
+                n = 0 if pid in self.glue else self.expected.get(pid, 0)
+                # a parameter that never reports gets its gradient through autograd glue at an unknown time: its
+                # bucket is left to finish()
+                self.pending[bi] = -1 if (n == 0 or self.pending[bi] < 0) else self.pending[bi] + n
         self.launched = [False] * self.nb
         self.handles = []
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
+        if self.world > 1 and not self._hooks:
+            # a gradient that autograd itself accumulates (glue ops around the kernels, e.g. `x + positional_embedding`
+            # in the masked-image pass) arrives at a time the kernels' reports say nothing about: such parameters keep
+            # their bucket for finish(), even when they ALSO report in-place contributions
+            # (a tensor hook fires only when autograd really delivers a gradient tensor for the leaf; the kernels'
+            # Functions return None for their parameters)
+            for p in self._params:
+                if p.requires_grad:
+                    self._hooks.append(p.register_hook(lambda g, p=p: self._on_autograd_grad(p, g)))
         return self
+
+    def _on_autograd_grad(self, p, g):
+        pid = id(p)
+        if g is not None and pid in self.bucket_of:
+            if self.expected is not None and pid not in self.glue and self.launched[self.bucket_of[pid]]:
+                self.late = self.store.names.get(pid, "?") if hasattr(self.store, "names") else "?"
+            self.glue.add(pid)
+        return None
 
     def detach(self):
         ops.grad_ready_hook = None
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def _launch(self, bi):
         if self.launched[bi]:
@@ -70,10 +112,17 @@ class FlatGradReducer:
 
     def on_grad_ready(self, p):
         pid = id(p)
-        if pid in self.seen or pid not in self.bucket_of:
+        if pid not in self.bucket_of:
             return
-        self.seen.add(pid)
+        c = self.count.get(pid, 0) + 1
+        self.count[pid] = c
+        if self.expected is None:
+            return
         bi = self.bucket_of[pid]
+        if c > self.expected.get(pid, 0):
+            if self.launched[bi]:   # a contribution landed after the bucket's all-reduce was issued
+                self.late = self.store.names.get(pid, "?") if hasattr(self.store, "names") else "?"
+            return
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.overlap:
             self._launch(bi)
@@ -85,6 +134,13 @@ class FlatGradReducer:
                 self._launch(bi)
             for h in self.handles:
                 h.wait()
+        if self.late is not None:
+            name, self.late = self.late, None
+            raise RuntimeError(f"gradient of {name!r} was accumulated after its bucket had been all-reduced (more "
+                               "contributions than on the reducer's first step): call reducer.relearn() when the set of "
+                               "objectives changes")
+        if self.expected is None:
+            self.expected = dict(self.count)
         self.reset()
 
     @property

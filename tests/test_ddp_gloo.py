@@ -67,17 +67,25 @@ def _worker(rank, world, port, bucket_bytes, out):
         store = FakeStore(named)
         red = FlatGradReducer(store, bucket_bytes=bucket_bytes).attach()
         assert red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
-        for step in range(2):
+        for step in range(3):
             store.grad.zero_()
-            # "backward": gradients appear in reverse parameter order, each reported once
+            # "backward": gradients appear in reverse parameter order; one parameter receives TWO in-place
+            # contributions per step (a weight used twice) and reports after each
             launched_before_finish = 0
             for i, (n, p) in enumerate(reversed(named)):
-                p.grad.fill_(float(rank + 1) * (i + 1) + step)
                 if n == "vqa_head.0.bias":
+                    p.grad.fill_(float(rank + 1) * (i + 1) + step)
                     continue  # a gradient that flows through autograd glue never reports; finish() must cover it
+                if n == "language_encoder.encoder.layer.0.output.dense.weight":
+                    p.grad.fill_(1000.0)                       # first contribution
+                    red.on_grad_ready(p)
+                    bi = red.bucket_of[id(p)]
+                    assert not red.launched[bi]                # ... must not release the bucket
+                p.grad.fill_(float(rank + 1) * (i + 1) + step)
                 red.on_grad_ready(p)
-                red.on_grad_ready(p)  # duplicate reports are ignored
             launched_before_finish = sum(red.launched)
+            if step == 0:
+                assert launched_before_finish == 0             # learning step: everything waits for finish()
             red.finish()
             for i, (n, p) in enumerate(reversed(named)):
                 expect = sum(float(r + 1) * (i + 1) + step for r in range(world))

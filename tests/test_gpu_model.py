@@ -539,3 +539,65 @@ def test_decoder_head_training_mode_dropout():
     assert abs(l1 - l2) <= 1e-6 * abs(l1) and (g1 - g2).double().norm().item() <= 1e-5 * g1.double().norm().item()
     assert abs(l1 - l3) > 1e-7 * abs(l1) and abs(l1 - le) > 1e-7 * abs(le)
     assert abs(le - float(g["loss"])) < 2e-3 * float(g["loss"])
+
+
+@pytest.mark.parametrize("task", ["vqa", "pretrain"])
+def test_grad_reducer_hooks_on_the_real_backward(task, monkeypatch):
+    """The data-parallel reducer against the REAL backward's report pattern (single process: the collective is replaced
+    by a recorder).  Learning step: no early launch; afterwards buckets are released during backward, each exactly once,
+    and never before the last in-place contribution of their parameters -- including the pre-training step, where every
+    encoder parameter receives three contributions (MLM / MIM / ITM passes)."""
+    import torch.distributed as dist
+    from m3ae_amd import ops
+    from m3ae_amd.ddp import FlatGradReducer
+    if task == "vqa":
+        cfg = tiny_config(compute_dtype="bf16")
+        b = to_dev(tiny_batch())
+    else:
+        cfg = tiny_config(compute_dtype="bf16", loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0},
+                          mim_layer=1, mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
+        b = to_dev(tiny_batch(pretrain=True))
+    m = build(cfg, torch.bfloat16)
+    m.train()
+    red = FlatGradReducer(m.store, bucket_bytes=256 << 10)
+    red.world = 2                                   # pretend: exercise the hook path in one process
+    calls = []
+
+    class H:
+        def wait(self):
+            pass
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), float(t.double().abs().sum().item())))
+        return H()
+
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    red.attach()
+    try:
+        for step in range(3):
+            m.store.zero_grad()
+            calls.clear()
+            ops.set_dropout_seed(5)
+            loss = m.training_step(b)
+            loss.backward()
+            early = len(calls)
+            snap = {c[0]: c[2] for c in calls}      # |grad| of each bucket at the moment it was released
+            red.finish()
+            assert len(calls) == red.nb              # every bucket exactly once
+            if step == 0:
+                assert early == 0 and red.expected is not None
+                if task == "pretrain":
+                    n = m.store.names
+                    w = m.language_encoder.encoder.layer[0].intermediate.dense.weight
+                    assert red.expected[id(w)] == 3, red.expected[id(w)]
+            else:
+                assert early >= red.nb // 2, (early, red.nb)
+                # a bucket released early already held its FINAL gradient
+                for bi in range(red.nb):
+                    a, e = red.bounds[bi], red.bounds[bi + 1]
+                    ptr = m.store.grad[a:e].data_ptr()
+                    if ptr in snap:
+                        final = float(m.store.grad[a:e].double().abs().sum().item())
+                        assert abs(snap[ptr] - final) <= 1e-9 * max(final, 1.0), (bi, snap[ptr], final)
+    finally:
+        red.detach()
