@@ -47,7 +47,7 @@ def clip_resize_crop(img, size):
         img = img.resize((nw, nh), Image.BICUBIC)
     top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
     img = img.crop((left, top, left + size, top + size)).convert("RGB")
-    return np.asarray(img, dtype=np.uint8)
+    return np.array(img, dtype=np.uint8)  # a writable copy (torch.from_numpy)
 
 
 def normalize_on_device(u8_nhwc, stream=None):

@@ -25,7 +25,6 @@ the GPU); `data_root=synthetic` (or empty) selects `SyntheticDataModule`, which 
 same collate schema (base_dataset.py:165-228).
 """
 import json
-import math
 import os
 import sys
 import time

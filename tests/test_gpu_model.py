@@ -386,7 +386,7 @@ def test_input_pipeline_device_tail_and_trainer_on_arrow_data(tmp_path):
     # same sample through the dataset directly == through the prefetching loader (order of epoch 0 is seeded)
     order = dm._indices(dm.train_set, 0, True)
     s = dm.train_set[order[0]]
-    want = (torch.from_numpy(s["image_u8"]).permute(2, 0, 1).float().div(255) - mean[0].cpu()) / std[0].cpu()
+    want = (torch.from_numpy(s["image_u8"].copy()).permute(2, 0, 1).float().div(255) - mean[0].cpu()) / std[0].cpu()
     assert torch.equal(b0["image"][0][0].cpu(), want) and b0["text_ids"][0].tolist() == s["input_ids"]
     tiny = ("image_size=64 hidden_size=128 num_heads=2 num_top_layer=2 input_image_embed_size=128 "
             "input_text_embed_size=128 vocab_size=1000 vit_width=128 vit_layers=3 text_hidden=128 text_layers=2 "
