@@ -257,48 +257,48 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
 // 68-float rows: conflict-free ds_write_b128 / ds_read_b128) so that every global access of the epilogue is
 // 8 lanes x 16 B = one whole 128-B line per row (the direct fragment layout touches 16 lines per instruction, 32 B
 // each, and made the N = 3072 GELU GEMMs store-issue bound).
-template <typename TC, int EPI, int MI>
+template <typename TC, int EPI, int MI, int RT = 2>   // RT: 16-row tiles per slab pass (slab = 16 RT rows x 68 floats)
 DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int64_t m_base, int64_t n_base,
                           f32x4 (&acc)[MI][4]) {
     constexpr int LDW = 68;
     constexpr bool BF = sizeof(TC) == 2;
     constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_DMUL);
-    float* t = (float*)smem + wave * 32 * LDW;
+    float* t = (float*)smem + wave * (16 * RT) * LDW;
     const int64_t ncol = n_base + (lane & 7) * 8;
     // everything the epilogue reads from global memory is requested up front: the wave waits for DRAM once
     float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (a.bias && ncol < a.N) Vec8<float>::ld(a.bias + ncol, bias8);
     const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
     const bool has_pre = BF && src != nullptr;
-    u32x4 pre[MI / 2][4];
+    u32x4 pre[MI / RT][2 * RT];
 #pragma unroll
-    for (int half = 0; half < MI / 2; ++half)
+    for (int half = 0; half < MI / RT; ++half)
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) pre[half][pass] = (u32x4){0u, 0u, 0u, 0u};
+        for (int pass = 0; pass < 2 * RT; ++pass) pre[half][pass] = (u32x4){0u, 0u, 0u, 0u};
     if (has_pre) {
 #pragma unroll
-        for (int half = 0; half < MI / 2; ++half)
+        for (int half = 0; half < MI / RT; ++half)
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int64_t m = m_base + 32 * half + pass * 8 + (lane >> 3);
+            for (int pass = 0; pass < 2 * RT; ++pass) {
+                const int64_t m = m_base + 16 * RT * half + pass * 8 + (lane >> 3);
                 if (m < a.M && ncol < a.N) pre[half][pass] = *(const u32x4*)(src + m * a.ldc + ncol);
             }
     }
 #pragma unroll
-    for (int half = 0; half < MI / 2; ++half) {
+    for (int half = 0; half < MI / RT; ++half) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < RT; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(f32x4*)(t + (16 * ii + (lane & 15)) * LDW + 16 * j + 4 * (lane >> 4)) = acc[2 * half + ii][j];
+                *(f32x4*)(t + (16 * ii + (lane & 15)) * LDW + 16 * j + 4 * (lane >> 4)) = acc[RT * half + ii][j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < 2 * RT; ++pass) {
             const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
             const f32x4 v0 = *(const f32x4*)(t + row * LDW + col);
             const f32x4 v1 = *(const f32x4*)(t + row * LDW + col + 4);
             float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int64_t m = m_base + 32 * half + row, n = n_base + col;
+            const int64_t m = m_base + 16 * RT * half + row, n = n_base + col;
             if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x, bias8, has_pre, pre[half][pass]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -736,6 +736,153 @@ static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
     return hip_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of gemm_nt_pp_kernel: one workgroup per CU walks tiles v = block, block + grid, ... (grid a multiple of
+// 8, so every tile of a workgroup maps to the same XCD range as in the one-tile-per-workgroup launch).  A K = 768 tile
+// spends ~12 % of its time waiting for its first chunks and ~16-30 % in the epilogue: here the NEXT tile's chunks 0 and 1
+// are requested before the epilogue of the current one (ring slots 2, 3; the epilogue's 16-row slabs live in slots
+// 0, 1), chunk 2 right after it, so the main loop of the next tile starts on landed data.
+// Ring slot of chunk c is (c + 2) & 3; everything else is the schedule of gemm_nt_pp_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs a) {
+    constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned tiles_n = (unsigned)((a.N + 255) / 256);
+    const unsigned tiles_m = (unsigned)((a.M + 255) / 256);
+    const unsigned total = tiles_m * tiles_n;
+    const int nc = (int)(a.K / CK);   // >= 3 (host check)
+    const int frow = lane & 15, fchunk = lane >> 4;
+
+    unsigned v = blockIdx.x;
+    unsigned tm, tn;
+    nt_tile_coords(xcd_remap(v, total), tiles_m, tiles_n, tm, tn);
+    int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        char* sl = smem + ((c + 2) & 3) * SLOT;
+        nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wave, lane);
+        nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wave, lane);
+    }
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // chunk 0 (and 1) of this tile: everything but the youngest 8 memory operations has completed
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+        for (int c = 0; c < nc; ++c) {
+            const char* At = smem + ((c + 2) & 3) * SLOT;
+            const char* Bt = At + A_BYTES;
+            char* nxt = smem + ((c + 5) & 3) * SLOT;
+            const bool more = c + 3 < nc;
+            s16x8 bfr[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<CK>(Bt, wc * 64 + j * 16 + frow, fchunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + i * 16 + frow, fchunk);
+            if (more) nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES, wave, lane);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
+            if (more) nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt, wave, lane);
+            {
+                const int rem = nc - 1 - c;
+                if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+        }
+        if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+        // every fragment read of this tile is retired, no DMA outstanding: request the next tile's chunks 0, 1 (slots 2, 3)
+        const unsigned vn = v + gridDim.x;
+        const bool again = vn < total;
+        const int64_t m_cur = m0, n_cur = n0;
+        if (again) {
+            nt_tile_coords(xcd_remap(vn, total), tiles_m, tiles_n, tm, tn);
+            m0 = (int64_t)tm * 256; n0 = (int64_t)tn * 256;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                char* sl = smem + ((c + 2) & 3) * SLOT;
+                nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wave, lane);
+                nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wave, lane);
+            }
+        }
+        if (a.c_f32) epilogue_rows<float, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
+        else epilogue_rows<bf16_t, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
+        if (!again) break;
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();   // every wave is done with its slab (slots 0, 1): chunk 2 may land in slot 0
+        PP_FENCE();
+        {
+            char* sl = smem + ((2 + 2) & 3) * SLOT;
+            nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)2 * CK, sl + A_BYTES, wave, lane);
+            nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)2 * CK, sl, wave, lane);
+        }
+        v = vn;
+    }
+}
+
+template <int EPI>
+static int launch_nt_pp_persistent(const MfmaArgs& a, hipStream_t s) {
+    constexpr int lds = 4 * (256 + 256) * 32 * 2;
+    static bool attr_set = false;
+    static int cus = 256;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_persistent_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount / 8 * 8;
+        attr_set = true;
+    }
+    g_last_path = "mfma_nt_pp";
+    hipLaunchKernelGGL((gemm_nt_pp_persistent_kernel<EPI>), dim3((unsigned)cus), dim3(512), lds, s, a);
+    return hip_launch_status();
+}
+
 // variants (m3ae_set_tuning key 0):
 //   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU (small / few-tile shapes)
 //   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU (the ping-pong kernel's
@@ -751,10 +898,15 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const bool big = cdiv(a.M, 256) * cdiv(a.N, 256) >= 512;
         // ping-pong kernel (variant 7): 1232 / 1340 TF/s at 4096^3 / 8192^3, +3..10 % over the 2-stage kernel on the
         // path's own shapes (profiles/r01_gemm_shapes.log)
-        if (big) return launch_nt_pp<EPI>(a, s);
+        static const int persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
+        if (big && persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
+        if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
     if (g_nt_variant == 7 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);  // ping-pong 8-phase
+    if (g_nt_variant == 8 && a.rows_epi && a.K >= 96 && cdiv(a.M, 256) * cdiv(a.N, 256) >= 512)
+        return launch_nt_pp_persistent<EPI>(a, s);                                    // persistent ping-pong
+    if (g_nt_variant == 8 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
     return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
 }
