@@ -201,11 +201,11 @@ def main():
                 f"{2.0 * M_ * N_ * K_ * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s, total {ms_ / 2:7.2f} ms/step")
         kern_table = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                       for k, v in agg.items() if v[1] > 0}
-        dom = "gemm:mfma_nt_pp"  # the dominant kernel of the step: gemm_nt_pp_kernel (all epilogue instantiations)
+        dom = "gemm:mfma_nt_pp"  # the dominant kernel of the step: gemm_nt_pp(_persistent)_kernel, all epilogue instantiations
         if dom in agg:
             n, ms, fl = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel", "achieved": round(ach, 1),
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_persistent_kernel", "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": None, "launches": n // 2, "avg_launch_ms": round(ms / n, 4),
                         "flops_per_launch": fl / n}

@@ -48,7 +48,7 @@ def main():
                          "requests at 64 B), both KiB -> bytes; calibrated on adamw_kernel (16 B read / 14 B written per "
                          "parameter: 5.15 GB / 4.51 GB per step measured vs 5.15 / 4.51 expected); fabric-side counters, "
                          "Infinity-Cache hits included",
-               "gemm_nt_pp_kernel": summary(fetch, write, "gemm_nt_pp_kernel"),
+               "gemm_nt_pp_kernel": summary(fetch, write, "gemm_nt_pp"),   # one-tile and persistent forms, all epilogues
                "gemm_nt_bf16_kernel": summary(fetch, write, "gemm_nt_bf16_kernel"),
                "gemm_tn_pp_kernel": summary(fetch, write, "gemm_tn_pp_kernel"),
                "gemm_tn_bf16_kernel": summary(fetch, write, "gemm_tn_bf16_kernel"),
