@@ -769,14 +769,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wave, lane);
         nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wave, lane);
     }
+    int top_wait = 0;
+    // stores per wave of an interior tile's epilogue: 16 row groups x (C [+ pre-activation / derivative]); bf16 only
+    const int interior_wait = a.c_f32 ? 1 : (a.preact ? 3 : 2);
     for (;;) {
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // chunk 0 (and 1) of this tile: everything but the youngest 8 memory operations has completed
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // chunks 0 (and 1) of this tile have landed.  vmcnt retires in order, so the wait names how many YOUNGER operations
+        // may stay in flight: chunks 1, 2 on the first tile; afterwards chunk 2 plus -- when the previous tile was an
+        // interior one, whose epilogue issued a known number of stores -- those stores (no store drain before the main loop)
+        if (top_wait == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (top_wait == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (top_wait == 3) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         PP_FENCE();
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
@@ -852,6 +860,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         if (a.c_f32) epilogue_rows<float, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
         else epilogue_rows<bf16_t, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
         if (!again) break;
+        top_wait = (m_cur + 256 <= a.M && n_cur + 256 <= a.N) ? interior_wait : 1;
         PP_FENCE();
         __builtin_amdgcn_s_barrier();   // every wave is done with its slab (slots 0, 1): chunk 2 may land in slot 0
         PP_FENCE();
