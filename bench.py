@@ -75,6 +75,8 @@ def main():
                     help="cls: configs[1] full fine-tune with the classification head (default, the timed metric); "
                          "t5: configs[2] frozen M3AE + T5 generative head (main_t5_m3ae.py recipe)")
     ap.add_argument("--t5", default="t5-small", help="t5-small (reference-faithful) | t5-base (BASELINE configs[2])")
+    ap.add_argument("--arch", choices=["base", "large"], default="base",
+                    help="large: configs[4] towers (ViT-L/16 + RoBERTa-large, 512x512; fusion stays 768 / 6 layers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
@@ -104,6 +106,12 @@ def main():
         from m3ae_amd.config import compose
         cfg = compose("task_pretrain_m3ae", "clip16", "text_roberta", image_size=384, max_text_len=64, compute_dtype="bf16")
         args.no_cpu_baseline = args.no_roofline = True
+    if args.arch == "large":  # configs[4]: no named config changes the fusion stack (config.py:45-51)
+        from m3ae_amd.config import compose
+        cfg = compose("task_finetune_vqa_vqa_rad", "clip16", "text_roberta", vit="ViT-L/16", tokenizer="roberta-large",
+                      input_image_embed_size=1024, input_text_embed_size=1024, image_size=512, compute_dtype="bf16",
+                      t5_model_name=args.t5)
+        args.no_cpu_baseline = args.no_roofline = True
     if args.head == "t5":
         from m3ae_amd.modules import T5VQA_MMEncoderInput
         model = T5VQA_MMEncoderInput(cfg)
@@ -121,7 +129,7 @@ def main():
 
     log("model resident; generating synthetic batch")
     B = args.batch
-    batch = to_dev(synth.synthetic_batch(B, text_len=cfg["max_text_len"], image_size=384, rank=rank,
+    batch = to_dev(synth.synthetic_batch(B, text_len=cfg["max_text_len"], image_size=cfg["image_size"], rank=rank,
                                          pretrain=args.head == "pretrain"), dev)
     batch["vqa_targets"] = build_vqa_targets(batch, cfg["vqa_label_size"], dev)
     if args.head == "t5":
@@ -292,6 +300,11 @@ def main():
             "final_loss": round(final_loss, 4),
             "roofline": roofline, "cross_attention_fwd": xattn, "kernels": kern_table, "cpu_baseline": cpu,
         }
+        if args.arch == "large":   # configs[4] towers: relabel (the numbers are not the headline metric)
+            line["metric"] = line["metric"].replace("M3AE-base", "M3AE (ViT-L/16 + RoBERTa-large towers)").replace("@384px", "@512px")
+            line["config"]["workload"] = ("configs[4] towers: ViT-L/16 (23 blocks, width 1024) + RoBERTa-large + 6 co-attention "
+                                          "layers (768), 512x512 (1025 image tokens), head: " + args.head +
+                                          (" " + args.t5 if args.head == "t5" else ""))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 runs the roofline / cpu_baseline legs alone; the others wait here, not in teardown
