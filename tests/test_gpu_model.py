@@ -601,3 +601,57 @@ def test_grad_reducer_hooks_on_the_real_backward(task, monkeypatch):
                         assert abs(snap[ptr] - final) <= 1e-9 * max(final, 1.0), (bi, snap[ptr], final)
     finally:
         red.detach()
+
+
+def test_grad_reducer_over_rccl_single_rank_group():
+    """The reducer on the REAL backend (`nccl` == RCCL) in a one-rank group on the GPU: the bucket all-reduces are issued
+    asynchronously from the backward hooks on RCCL's stream, `finish()` joins them, and three optimizer steps give the
+    losses of the same three steps without any reducer.  (A one-rank sum is the identity: what this covers is the API /
+    stream-ordering path bench.py and the trainer use for N > 1, which the gloo tests cannot.)"""
+    import torch.distributed as dist
+    from m3ae_amd import ops
+    from m3ae_amd.ddp import FlatGradReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = tiny_config(compute_dtype="bf16")
+        b = to_dev(tiny_batch())
+
+        def run(with_reducer):
+            m = build(cfg, torch.bfloat16)
+            m.train()
+            red = None
+            if with_reducer:
+                red = FlatGradReducer(m.store, bucket_bytes=128 << 10)
+                red.world = 2                      # take the hook path; the group itself has one rank
+                red.attach()
+            losses = []
+            try:
+                for step in range(3):
+                    m.store.zero_grad()
+                    ops.set_dropout_seed(11 + step)
+                    loss = m.training_step(b)
+                    loss.backward()
+                    if red is not None:
+                        early = sum(red.launched)
+                        red.finish()
+                        assert (early == 0) if step == 0 else (early >= red.nb // 2), (step, early, red.nb)
+                    m.store.adamw_step(max_steps=10, grad_scale=1.0)
+                    losses.append(loss.item())
+            finally:
+                if red is not None:
+                    red.detach()
+            return losses, m.store.flat.detach().clone()
+
+        l0, p0 = run(False)
+        l1, p1 = run(True)
+        # fp32 atomics in the split reductions: run-to-run differences of a few ulp are expected, nothing more
+        assert np.allclose(l0, l1, rtol=1e-5, atol=0), (l0, l1)
+        assert torch.allclose(p0, p1, rtol=0, atol=2e-5), float((p0 - p1).abs().max())
+    finally:
+        if own_group:
+            dist.destroy_process_group()
