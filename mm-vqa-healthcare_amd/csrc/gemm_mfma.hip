@@ -567,12 +567,18 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int m3ae_attn_set_coop(int v);
 static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : -1;
 static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
+// persistent form of the ping-pong kernel (static tile lists, one workgroup per CU): OFF for data-parallel runs
+// (m3ae_set_tuning key 6, set by ddp.FlatGradReducer) -- when RCCL's kernels hold some CUs the persistent workgroups
+// that found no CU only start after others have walked their whole tile list (the kernel's time doubles); the
+// one-tile-per-workgroup launch just runs on the CUs that are free
+static int g_nt_persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
 static int g_nt_trace = 0;
 static int g_stagger_ticks = -1;   // -1: from K (launch_nt_dual)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
     if (key == 4) { g_stagger_ticks = value; return 0; }
     if (key == 5) { g_nt_trace = value; return 0; }
+    if (key == 6) { g_nt_persist = value; return 0; }
     if (key == 1) { g_tn_variant = value; return 0; }
     if (key == 2) return m3ae_attn_set_coop(value);
     return M3AE_ERR_ARG;
@@ -1059,8 +1065,7 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const bool big = cdiv(a.M, 256) * cdiv(a.N, 256) >= 512;
         // ping-pong kernel (variant 7): 1232 / 1340 TF/s at 4096^3 / 8192^3, +3..10 % over the 2-stage kernel on the
         // path's own shapes (profiles/r01_gemm_shapes.log)
-        static const int persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
-        if (big && persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
+        if (big && g_nt_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }

@@ -76,6 +76,11 @@ class FlatGradReducer:
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
+        if self.world > 1 and torch.cuda.is_available():
+            # RCCL's kernels run next to backward and hold some CUs: the persistent NT kernel (static tile lists, one
+            # workgroup per CU) would wait for them with a whole tile list in hand; use the one-tile-per-workgroup launch
+            from . import _lib
+            _lib.lib().m3ae_set_tuning(6, 0)
         if self.world > 1 and not self._hooks:
             # a gradient that autograd itself accumulates (glue ops around the kernels, e.g. `x + positional_embedding`
             # in the masked-image pass) arrives at a time the kernels' reports say nothing about: such parameters keep

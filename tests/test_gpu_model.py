@@ -601,6 +601,8 @@ def test_grad_reducer_hooks_on_the_real_backward(task, monkeypatch):
                         assert abs(snap[ptr] - final) <= 1e-9 * max(final, 1.0), (bi, snap[ptr], final)
     finally:
         red.detach()
+        from m3ae_amd import _lib
+        _lib.lib().m3ae_set_tuning(6, 1)   # attach() with world > 1 turned the persistent NT kernel off
 
 
 def test_grad_reducer_over_rccl_single_rank_group():
@@ -645,6 +647,8 @@ def test_grad_reducer_over_rccl_single_rank_group():
             finally:
                 if red is not None:
                     red.detach()
+                    from m3ae_amd import _lib
+                    _lib.lib().m3ae_set_tuning(6, 1)
             return losses, m.store.flat.detach().clone()
 
         l0, p0 = run(False)
