@@ -9,7 +9,11 @@ Reference pieces restated (host side, Python like the reference's):
   * `VQAVQARADDataset.__getitem__` (vqa_vqa_rad_dataset.py:24-43);
   * `clip_transform` (transforms/transform.py:60-67): PIL RGBA -> `Resize(size, BICUBIC)` (shorter side, torchvision's
     integer rounding) -> `CenterCrop(size)` -> RGB -> ToTensor -> Normalize(CLIP mean / std);
-  * `collate` (base_dataset.py:165-228) for the fine-tuning keys (`*_mlm` fields only for pre-training: not built).
+  * `collate` (base_dataset.py:165-228): fine-tuning keys, and with an `MLMCollator` the pre-training fields
+    `text_ids_mlm` / `text_labels_mlm`;
+  * the masked-language-model collators the datamodule picks (base_datamodule.py:62-69, third-party transformers==4.6.0
+    `DataCollatorForWholeWordMask` / `DataCollatorForLanguageModeling`; the reference vendors the same file as
+    m3ae/utils/data_collator.py:290-496) -> `MLMCollator`.
 
 MI355X side: decode + bicubic resize stay on host cores (PIL releases the GIL; a thread pool of `num_workers`), the
 crop is handed over as uint8 NHWC in PINNED memory (a quarter of the fp32 bytes over PCIe), copied on a side HIP
@@ -75,6 +79,85 @@ def load_tokenizer(cfg):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# masked-language-model collation (pre-training batches)
+# ------------------------------------------------------------------------------------------------------------
+class MLMCollator:
+    """`mlm_collator` of base_datamodule.py:62-69, restated (host side; consumes Python's `random` and torch's CPU
+    generator in the release's order, so a seeded run reproduces the release's draws -- tests/golden/mlm_collate.npz).
+
+    whole_word=True (config.py:40): data_collator.py:381-496.  Per example, candidate words are runs of a token followed
+    by its "##" continuations; "[CLS]" / "[SEP]" are skipped BY NAME, so with the RoBERTa vocabulary (no "##", specials
+    called <s> </s> <pad>) every position -- specials and padding included -- is a one-token candidate.  The candidates are
+    shuffled and taken until max(1, round(len * p)) positions are covered (len = the PADDED length the dataset
+    produced, base_dataset.py:154-163), then specials and padding are struck from the selection: a short question
+    ends up with fewer masked tokens than the count suggests.  Quirks kept as they are.
+    whole_word=False: data_collator.py:290-378, Bernoulli(p) per non-special position.
+    Both: selected positions keep their id as label (-100 elsewhere) and are rewritten 80 % -> <mask>, 10 % -> a uniform
+    random id, 10 % unchanged."""
+
+    def __init__(self, tokenizer, mlm_probability=0.15, whole_word=True, max_predictions=512):
+        self.tok, self.p, self.whole_word, self.max_predictions = tokenizer, mlm_probability, whole_word, max_predictions
+        if getattr(tokenizer, "mask_token_id", None) is None:
+            raise ValueError("masked language modelling needs a tokenizer with a mask token")
+
+    def _pad(self, rows):
+        """_collate_batch (data_collator.py:253-287): right-pad with pad_token_id to the longest row."""
+        n = max(len(r) for r in rows)
+        out = torch.full((len(rows), n), int(self.tok.pad_token_id), dtype=torch.long)
+        for i, r in enumerate(rows):
+            out[i, : len(r)] = torch.as_tensor(r, dtype=torch.long)
+        return out
+
+    def _special(self, ids):
+        return torch.tensor([self.tok.get_special_tokens_mask(r, already_has_special_tokens=True) for r in ids.tolist()],
+                            dtype=torch.bool)
+
+    def _word_selection(self, tokens):
+        words = []
+        for i, t in enumerate(tokens):
+            if t in ("[CLS]", "[SEP]"):
+                continue
+            if words and t.startswith("##"):
+                words[-1].append(i)
+            else:
+                words.append([i])
+        random.shuffle(words)
+        budget = min(self.max_predictions, max(1, int(round(len(tokens) * self.p))))
+        chosen = []
+        for w in words:
+            if len(chosen) >= budget:
+                break
+            if len(chosen) + len(w) > budget or any(i in chosen for i in w):
+                continue
+            chosen.extend(w)
+        sel = [0] * len(tokens)
+        for i in chosen:
+            sel[i] = 1
+        return sel
+
+    def __call__(self, encodings):
+        rows = [list(e["input_ids"]) if isinstance(e, dict) else list(e) for e in encodings]
+        ids = self._pad(rows)
+        labels = ids.clone()
+        if self.whole_word:
+            # the selection rows are padded with pad_token_id too (any non-zero reads as "selected"); padding is struck below
+            picked = self._pad([self._word_selection(self.tok.convert_ids_to_tokens(r)) for r in rows])
+            picked.masked_fill_(self._special(labels), 0)
+            picked.masked_fill_(labels.eq(int(self.tok.pad_token_id)), 0)
+            picked = picked.bool()
+        else:
+            prob = torch.full(labels.shape, self.p)
+            prob.masked_fill_(self._special(labels), 0.0)
+            picked = torch.bernoulli(prob).bool()
+        labels[~picked] = -100
+        to_mask = torch.bernoulli(torch.full(labels.shape, 0.8)).bool() & picked
+        ids[to_mask] = int(self.tok.mask_token_id)
+        to_random = torch.bernoulli(torch.full(labels.shape, 0.5)).bool() & picked & ~to_mask
+        ids[to_random] = torch.randint(len(self.tok), labels.shape, dtype=torch.long)[to_random]
+        return {"input_ids": ids, "labels": labels}
+
+
+# ------------------------------------------------------------------------------------------------------------
 # dataset
 # ------------------------------------------------------------------------------------------------------------
 class ArrowVQADataset:
@@ -120,8 +203,10 @@ class ArrowVQADataset:
         }
 
 
-def collate_host(samples, pin=True):
-    """base_dataset.py:165-228 (fine-tuning keys): images stacked as uint8 NHWC, ids / masks as int64 tensors."""
+def collate_host(samples, pin=True, mlm_collator=None):
+    """base_dataset.py:165-228: images stacked as uint8 NHWC, ids / masks as int64 tensors; with `mlm_collator` also
+    `text_ids_mlm` / `text_labels_mlm` (:202-209; the reference always computes them, the fine-tuning step never reads
+    them)."""
     B = len(samples)
     S = max(len(s["input_ids"]) for s in samples)
     img = torch.from_numpy(np.stack([s["image_u8"] for s in samples]))
@@ -130,9 +215,14 @@ def collate_host(samples, pin=True):
     for i, s in enumerate(samples):
         ids[i, : len(s["input_ids"])] = torch.tensor(s["input_ids"])
         mask[i, : len(s["attention_mask"])] = torch.tensor(s["attention_mask"])
+    extra = {}
+    if mlm_collator is not None:
+        m = mlm_collator([{"input_ids": s["input_ids"]} for s in samples])
+        extra = {"text_ids_mlm": m["input_ids"], "text_labels_mlm": m["labels"]}
     if pin and torch.cuda.is_available():
         img, ids, mask = img.pin_memory(), ids.pin_memory(), mask.pin_memory()
-    return {"image_u8": img, "text_ids": ids, "text_masks": mask,
+        extra = {k: v.pin_memory() for k, v in extra.items()}
+    return {"image_u8": img, "text_ids": ids, "text_masks": mask, **extra,
             "text": [s["text"] for s in samples],
             "vqa_answer": [s["vqa_answer"] for s in samples], "vqa_labels": [s["vqa_labels"] for s in samples],
             "vqa_scores": [s["vqa_scores"] for s in samples], "answer_types": [s["answer_types"] for s in samples],
@@ -148,9 +238,10 @@ def to_device_batch(hb, device, copy_stream=None):
         ids = hb["text_ids"].to(device, non_blocking=True)
         mask = hb["text_masks"].to(device, non_blocking=True)
         ev = torch.cuda.Event()
+        mlm = {k: hb[k].to(device, non_blocking=True) for k in ("text_ids_mlm", "text_labels_mlm") if k in hb}
         ev.record(cs)
-    out = {k: v for k, v in hb.items() if k not in ("image_u8", "text_ids", "text_masks")}
-    out.update(_u8=u8, text_ids=ids, text_masks=mask, text_labels=None, _ready=ev)
+    out = {k: v for k, v in hb.items() if k not in ("image_u8", "text_ids", "text_masks", "text_ids_mlm", "text_labels_mlm")}
+    out.update(_u8=u8, text_ids=ids, text_masks=mask, text_labels=None, _ready=ev, **mlm)
     return out
 
 
@@ -185,6 +276,10 @@ class ArrowDataModule:
         self.workers = max(int(cfg.get("num_workers", 8)), 1)
         self.prefetch = prefetch
         self.copy_stream = torch.cuda.Stream(device=device) if torch.cuda.is_available() else None
+        # base_datamodule.py:62-69; the reference builds it for every task, only the MLM objective reads its output
+        self.mlm_collator = None
+        if cfg.get("loss_names", {}).get("mlm", 0) > 0:
+            self.mlm_collator = MLMCollator(self.tokenizer, cfg.get("mlm_prob", 0.15), cfg.get("whole_word_masking", True))
 
     @staticmethod
     def _try(mk, split):
@@ -214,7 +309,7 @@ class ArrowDataModule:
                 for c in chunks:
                     if stop.is_set():
                         break
-                    q.put(collate_host(list(pool.map(ds.__getitem__, c))))
+                    q.put(collate_host(list(pool.map(ds.__getitem__, c)), mlm_collator=self.mlm_collator))
             q.put(None)
 
         th = threading.Thread(target=producer, daemon=True)

@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by importing and running the reference's own modules (build container only).
 
-TEST INFRASTRUCTURE ONLY.  Usage:  python oracle/make_golden.py [tiny] [full] [pretrain] [optim]
+TEST INFRASTRUCTURE ONLY.  Usage:  python oracle/make_golden.py [tiny] [full] [pretrain] [t5] [decoder] [t5gen] [mlm]
 
 Inputs and weights are NOT stored: they are regenerated bit-identically from
 m3ae_amd.synth (counter-based, keyed by tensor name).  Only the reference's OUTPUTS are stored:
@@ -397,8 +397,39 @@ def run_t5_generate():
 
 
 
+def run_mlm_collate():
+    """the masked-language-model collators the reference's datamodule instantiates
+    (base_datamodule.py:62-69) -- transformers==4.6.0 classes, vendored verbatim by the reference as
+    m3ae/utils/data_collator.py, which is what is imported and run here -- on stub tokenizers, seeded."""
+    import random
+    import numpy as np
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_collator", os.path.join(rs.REF_ROOT, "m3ae/utils/data_collator.py"))
+    dc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc)
+    out = {}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from arrow_util import CollatorTokenizer, collator_cases
+    for ci, (style, fixed, rows) in enumerate(collator_cases()):
+        tok = CollatorTokenizer(style)
+        for whole in (True, False):
+            cls = dc.DataCollatorForWholeWordMask if whole else dc.DataCollatorForLanguageModeling
+            coll = cls(tokenizer=tok, mlm=True, mlm_probability=0.15)
+            random.seed(100 + ci)
+            torch.manual_seed(200 + ci)
+            if whole:
+                r = coll([{"input_ids": list(x)} for x in rows])
+            else:   # the token-level class pads through tokenizer.pad for dicts; lists take its _collate_batch path
+                r = coll([torch.tensor(x) for x in rows])
+            k = f"c{ci}_{'wwm' if whole else 'tok'}"
+            out[k + "_ids"] = r["input_ids"].numpy()
+            out[k + "_labels"] = r["labels"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "mlm_collate.npz"), **out)
+    print("mlm_collate.npz:", len(out), "arrays")
+
+
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder", "t5gen"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder", "t5gen", "mlm"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -410,6 +441,8 @@ def main():
         run_decoder()
     if "t5gen" in what:
         run_t5_generate()
+    if "mlm" in what:
+        run_mlm_collate()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
 

@@ -63,3 +63,55 @@ def write_split(root, split, n_images, seed=0):
         with pa.RecordBatchFileWriter(sink, table.schema) as writer:
             writer.write_table(table)
     return qid
+
+
+class CollatorTokenizer:
+    """Just enough tokenizer for the collators: RoBERTa special ids / names, or BERT-style names with "##" pieces."""
+
+    def __init__(self, style, n=1000):
+        self.style, self.n = style, n
+        if style == "roberta":
+            self.names = {0: "<s>", 1: "<pad>", 2: "</s>", 3: "<unk>", n - 1: "<mask>"}
+            self.pad_token_id, self.mask_token_id = 1, n - 1
+            self.special = {0, 1, 2}
+        else:
+            self.names = {0: "[PAD]", 100: "[UNK]", 101: "[CLS]", 102: "[SEP]", 103: "[MASK]"}
+            self.pad_token_id, self.mask_token_id = 0, 103
+            self.special = {0, 101, 102}
+        self.mask_token, self._pad_token = self.names[self.mask_token_id], self.names[self.pad_token_id]
+        self.padding_side = "right"
+
+    def __len__(self):
+        return self.n
+
+    def _convert_id_to_token(self, i):
+        if i in self.names:
+            return self.names[i]
+        return ("##p%d" if self.style == "bert" and i % 3 == 0 else "w%d") % i
+
+    def convert_ids_to_tokens(self, ids):
+        return [self._convert_id_to_token(int(i)) for i in ids]
+
+    def convert_tokens_to_ids(self, t):
+        return {v: k for k, v in self.names.items()}[t]
+
+    def get_special_tokens_mask(self, ids, already_has_special_tokens=True):
+        return [1 if int(i) in self.special else 0 for i in ids]
+
+
+def collator_cases():
+    rng = np.random.RandomState(7)
+    cases = []
+    for style in ("roberta", "bert"):
+        tok = CollatorTokenizer(style)
+        first, last = (0, 2) if style == "roberta" else (101, 102)
+        for fixed in (True, False):     # padded to max_length by the dataset (the reference's case) / ragged
+            rows = []
+            for _ in range(6):
+                n = int(rng.randint(4, 31))
+                r = [first] + [int(v) for v in rng.randint(110, 990, size=n)] + [last]
+                if fixed:
+                    r += [tok.pad_token_id] * (32 - len(r))
+                rows.append(r)
+            cases.append((style, fixed, rows))
+    return cases

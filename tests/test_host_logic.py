@@ -139,3 +139,49 @@ def test_arrow_dataset_transform_and_collate(tmp_path):
     assert (hb["text_ids"][:, 0] == 0).all() and ((hb["text_ids"] == 1) == (hb["text_masks"] == 0)).all()
     assert hb["vqa_labels"][0] == [0] and hb["vqa_scores"][0] == [1.0] and hb["answer_types"][0] in (0, 1)
     assert isinstance(hb["vqa_answer"][0], list) and isinstance(hb["text"][0], str)
+
+
+def test_mlm_collator_matches_the_release_the_reference_uses():
+    """`MLMCollator` against tests/golden/mlm_collate.npz -- outputs of the collator classes the reference's
+    datamodule instantiates (base_datamodule.py:62-69), produced by oracle/make_golden.py from the reference's vendored
+    copy (m3ae/utils/data_collator.py) under the same seeds: whole-word and token-level masking, RoBERTa-style and
+    BERT-style ("##" pieces, [CLS] / [SEP]) vocabularies, max_length-padded and ragged batches.  Bit-exact."""
+    import random
+    from arrow_util import CollatorTokenizer, collator_cases
+    from m3ae_amd.data import MLMCollator
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mlm_collate.npz"))
+    masked_total = 0
+    for ci, (style, fixed, rows) in enumerate(collator_cases()):
+        tok = CollatorTokenizer(style)
+        for whole in (True, False):
+            random.seed(100 + ci)
+            torch.manual_seed(200 + ci)
+            out = MLMCollator(tok, 0.15, whole_word=whole)([{"input_ids": list(r)} for r in rows])
+            k = f"c{ci}_{'wwm' if whole else 'tok'}"
+            assert np.array_equal(out["input_ids"].numpy(), g[k + "_ids"]), k
+            assert np.array_equal(out["labels"].numpy(), g[k + "_labels"]), k
+            lab = out["labels"].numpy()
+            masked_total += int((lab != -100).sum())
+            # never a special or padding position; labels hold the ORIGINAL id
+            orig = np.full(lab.shape, tok.pad_token_id, dtype=np.int64)
+            for i, r in enumerate(rows):
+                orig[i, : len(r)] = r
+            sel = lab != -100
+            assert np.array_equal(lab[sel], orig[sel])
+            assert not any(int(v) in tok.special for v in orig[sel])
+    assert masked_total > 40
+
+
+def test_collate_host_adds_mlm_fields(tmp_path):
+    import random
+    from arrow_util import CollatorTokenizer, HashTokenizer, write_split
+    from m3ae_amd import data
+    write_split(str(tmp_path), "train", 4)
+    ds = data.ArrowVQADataset(str(tmp_path), "train", 32, 16, HashTokenizer())
+    random.seed(1)
+    torch.manual_seed(1)
+    hb = data.collate_host([ds[i] for i in range(4)], pin=False, mlm_collator=data.MLMCollator(CollatorTokenizer("roberta"), 0.3))
+    assert hb["text_ids_mlm"].shape == hb["text_ids"].shape == hb["text_labels_mlm"].shape
+    sel = hb["text_labels_mlm"] != -100
+    assert sel.any() and torch.equal(hb["text_labels_mlm"][sel], hb["text_ids"][sel])
+    assert torch.equal(hb["text_ids_mlm"][~sel], hb["text_ids"][~sel])
