@@ -50,6 +50,7 @@ struct MfmaArgs {
     int rows_epi;     // NT only: LDS-transposed row-contiguous epilogue (N % 8 == 0)
     int splits;       // TN only
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
+    int col_group;      // ping-pong NT kernels: column tiles per group of the tile order (nt_tile_coords)
     int trace;          // dual NT kernel: overwrite 28 B of every tile's first row with (hw_id, xcc_id, t0, t1, t2, block, clocks)
     int stagger_ticks;  // dual NT kernel: start-up delay of the second workgroup of every CU (100-MHz ticks)
 };
@@ -61,11 +62,11 @@ DEVINL unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
-// Tile order inside the (XCD-contiguous) id range: column tiles in groups of 4, row-major inside a group.  An XCD then
-// works against <= 4 column tiles of B (<= 1.5 MiB at K = 768: resident in its 4-MiB L2) while A streams, instead of
-// cycling through all of B for every row block (N = 3072: B = 4.7 MiB thrashed the L2 -- 7x the algorithmic reads, PMC).
-DEVINL void nt_tile_coords(unsigned wg, unsigned tiles_m, unsigned tiles_n, unsigned& tm, unsigned& tn) {
-    constexpr unsigned GC = 4;
+// Tile order inside the (XCD-contiguous) id range: column tiles in groups of GC, row-major inside a group.  An XCD then
+// works against <= GC column tiles of B (resident in its 4-MiB L2) while A streams, instead of cycling through all of B
+// for every row block (N = 3072: B = 4.7 MiB thrashed the L2 -- 7x the algorithmic reads, PMC); A is re-read once per
+// group.  GC: 4 for the generic kernels, by shape for the ping-pong kernels (launch_nt).
+DEVINL void nt_tile_coords(unsigned wg, unsigned tiles_m, unsigned tiles_n, unsigned& tm, unsigned& tn, unsigned GC = 4) {
     const unsigned per_group = tiles_m * GC;
     const unsigned g = wg / per_group;
     const unsigned first = g * GC;
@@ -572,6 +573,7 @@ static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIA
 // that found no CU only start after others have walked their whole tile list (the kernel's time doubles); the
 // one-tile-per-workgroup launch just runs on the CUs that are free
 static int g_nt_persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
+static int g_nt_col_group = 0;   // 0: by shape (launch_nt)
 static int g_nt_trace = 0;
 static int g_stagger_ticks = -1;   // -1: from K (launch_nt_dual)
 extern "C" int m3ae_set_tuning(int key, int value) {
@@ -579,6 +581,7 @@ extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 4) { g_stagger_ticks = value; return 0; }
     if (key == 5) { g_nt_trace = value; return 0; }
     if (key == 6) { g_nt_persist = value; return 0; }
+    if (key == 7) { g_nt_col_group = value; return 0; }
     if (key == 1) { g_tn_variant = value; return 0; }
     if (key == 2) return m3ae_attn_set_coop(value);
     return M3AE_ERR_ARG;
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
 
     const unsigned tiles_n = (unsigned)((a.N + 255) / 256);
     unsigned tm, tn;
-    nt_tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, tm, tn);
+    nt_tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, tm, tn, (unsigned)a.col_group);
     const int64_t m0 = (int64_t)tm * 256;
     const int64_t n0 = (int64_t)tn * 256;
 
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
 
     unsigned v = blockIdx.x;
     unsigned tm, tn;
-    nt_tile_coords(xcd_remap(v, total), tiles_m, tiles_n, tm, tn);
+    nt_tile_coords(xcd_remap(v, total), tiles_m, tiles_n, tm, tn, (unsigned)a.col_group);
     int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         const bool again = vn < total;
         const int64_t m_cur = m0, n_cur = n0;
         if (again) {
-            nt_tile_coords(xcd_remap(vn, total), tiles_m, tiles_n, tm, tn);
+            nt_tile_coords(xcd_remap(vn, total), tiles_m, tiles_n, tm, tn, (unsigned)a.col_group);
             m0 = (int64_t)tm * 256; n0 = (int64_t)tn * 256;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -1091,6 +1094,11 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.preact_grad = d.preact_grad;
     a.residual = d.residual; a.dact_aux = d.dact_aux; a.dact = d.dact;
     a.rows_epi = (d.N % 8 == 0 && d.c_sm % 8 == 0) ? 1 : 0;
+    {   // column tiles per group of the ping-pong kernels' tile order: all of them up to 9 (N <= 2304: B <= 3.4 MiB at
+        // K = 768), else 6 -- measured against 3 / 4 / 12 on the path's shapes (profiles/r01_nt_col_group.log: -3..5 %)
+        const int tiles_n = (int)((d.N + 255) / 256);
+        a.col_group = g_nt_col_group > 0 ? g_nt_col_group : (tiles_n <= 9 ? tiles_n : 6);
+    }
     a.has_drop = d.dropout_p > 0.f;
     a.drop = make_drop(d.dropout_p, d.dropout_seed);
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;

@@ -18,7 +18,7 @@ def main():
     dev = "cuda"
     cases = [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (2304, 768, "plain"), (768, 768, "bias+res"),
              (768, 3072, "bias+res"), (1536, 768, "plain")]
-    sweeps = [(8, 0), (9, 0), (9, 300), (9, 600), (9, 1200), (9, -1), (8, 0)]
+    sweeps = [(8, 0), (9, -1), (8, 0)] if not os.environ.get('GC') else [(8, int(g)) for g in os.environ['GC'].split(',')]
     for (n, k, kind) in cases:
         x = torch.randn(M, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
@@ -37,12 +37,13 @@ def main():
         out = []
         for d, tk in sweeps:
             L.m3ae_set_tuning(0, d)
-            L.m3ae_set_tuning(4, tk)
+            L.m3ae_set_tuning(7 if os.environ.get('GC') else 4, tk)
             ms = time_it(fn)
-            out.append(f"variant {d} stagger {tk}: {ms * 1e3:7.1f}us {2.0 * M * n * k / ms / 1e9:6.0f}TF")
+            out.append(f"variant {d} {'col-group' if os.environ.get('GC') else 'stagger'} {tk}: {ms * 1e3:7.1f}us {2.0 * M * n * k / ms / 1e9:6.0f}TF")
         print(f"NT {M}x{n}x{k} {kind:12s}\n   " + "\n   ".join(out), flush=True)
     L.m3ae_set_tuning(0, -1)
     L.m3ae_set_tuning(4, -1)
+    L.m3ae_set_tuning(7, 0)
 
 
 if __name__ == "__main__":
