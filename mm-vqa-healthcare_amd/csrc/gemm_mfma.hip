@@ -1058,8 +1058,13 @@ static int launch_nt_dual(const MfmaArgs& a0, hipStream_t s) {
 //   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU (the ping-pong kernel's
 //      bit-exact reference in tools/gemm_race.py)
 //   7: 256x256 tile, 32-deep chunks in a 4-slot ring, 8 waves in two staggered rows (ping-pong, gemm_nt_pp_kernel)
+//   9: 128x256 tile, 4 waves, two workgroups per CU, fragments software-pipelined in registers (gemm_nt_dual_kernel)
 // Tilings tried and dropped (measured slower on every shape of the path, r01 logs): 256x128 with BK 64 / 3 stages,
-// 256x128 with BK 32 / 2 and 3 stages, 256x256 with BK 32 / 4 stages (single barrier), 128x128 with BK 32.
+// 256x128 with BK 32 / 2 and 3 stages, 256x256 with BK 32 / 4 stages (single barrier), 128x128 with BK 32;
+// 256x256 with FOUR waves of 128x128 (256 accumulators pinned to AGPRs through asm constraints, one wave per SIMD, the
+// dual kernel's software pipeline, 33 % fewer LDS fragment bytes per MFMA): bit-identical, 1143 vs 1281 TF/s at 8192^3
+// and 12-25 % slower on the path's shapes (profiles/r01_nt_w4_probe.log) -- one wave per SIMD does not keep the MFMA
+// pipe as busy as the two staggered wave rows do.
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log

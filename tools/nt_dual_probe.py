@@ -18,7 +18,7 @@ def main():
     dev = "cuda"
     cases = [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (2304, 768, "plain"), (768, 768, "bias+res"),
              (768, 3072, "bias+res"), (1536, 768, "plain")]
-    sweeps = [(8, 0), (9, -1), (8, 0)] if not os.environ.get('GC') else [(8, int(g)) for g in os.environ['GC'].split(',')]
+    sweeps = [(int(v), -1) for v in os.environ.get('VARS', '8,9,8').split(',')] if not os.environ.get('GC') else [(8, int(g)) for g in os.environ['GC'].split(',')]
     for (n, k, kind) in cases:
         x = torch.randn(M, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
