@@ -226,6 +226,16 @@ def main():
                 if tj.get("per_gpu_batch") == B and tj.get("head") == args.head:
                     roofline["traffic"] = tj["gemm_nt_pp_kernel"]["bytes_per_launch"]
                     roofline["traffic_unit"] = "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; " + tp[len(ROOT) + 1:] + ")"
+                    # MFMA-pipe busy fraction and effective clock of the same kernel from the committed counter pass
+                    # (tools/pmc_mfma.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))
+                    mp = os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")
+                    if os.path.exists(mp):
+                        with open(mp) as f:
+                            mk = [v for k, v in json.load(f)["kernels"].items() if k.startswith("gemm_nt_pp")]
+                        ms_ = sum(v["total_ms"] for v in mk)
+                        if ms_ > 0:
+                            roofline["mfma_busy_pmc"] = round(sum(v["mfma_util"] * v["total_ms"] for v in mk) / ms_, 3)
+                            roofline["clock_mhz_pmc"] = round(sum(v["clock_mhz"] * v["total_ms"] for v in mk) / ms_)
         # fused cross-attention forward (all 6 layers, both directions), HIP events around the sub-blocks
         m3 = model.m3ae if args.head == "t5" else model
         with torch.no_grad():
