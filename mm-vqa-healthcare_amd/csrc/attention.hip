@@ -53,6 +53,11 @@ DEVINL f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
 // accumulator register `reg` of lane half `h` holds ROW crow(reg, h) of a 32x32 tile (column = lane & 31)
 DEVINL int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// value of lane J of the caller's quad (lanes 4 m .. 4 m + 3), by DPP: one VALU move, no LDS
+template <int J> DEVINL uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true);
+}
+
 // bf16 B-operand fragment for k-step s from accumulator registers 8s..8s+7 (k order = crow order)
 DEVINL s16x8 pack_acc(const f32x16& p, int s) {
     u32x4 w;
@@ -895,6 +900,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP[q][key] = dO . V^T
             f32x16 p;
+            // Dropout mask of (query row, key): hash of the GROUP (row * ld + key) >> 2 = row * (ld / 4) + (key >> 2), byte
+            // key & 3.  A lane owns ONE key and 16 rows, so per lane every element has its own group -- but the four lanes
+            // of a quad own the four keys of one group: each lane hashes the 4 rows (reg & 3) == (lane & 3) and the quad
+            // shares them by DPP (4 hashes + 16 moves per lane and tile instead of 16 hashes with 64-bit index products:
+            // the dropout instances ran 1.9x the time of the plain ones, VALU-bound).  Rows past Lq / keys past Lk carry
+            // p = 0: their mask value never matters, so no clamping.
+            uint32_t hq[4] = {0u, 0u, 0u, 0u};
+            if (DROP) {
+                const uint64_t ldq = (uint64_t)(drop_ldk(a.Lk) >> 2);
+                const uint64_t g0 = (uint64_t)((b * a.H + head) * a.Lq + (int64_t)qt * 32 + 4 * h + (lane & 3)) * ldq +
+                                    (uint64_t)((k0 + (r & ~3)) >> 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hq[g] = drop_hash(a.drop, g0 + (uint64_t)(8 * g) * ldq);
+            }
+            const uint32_t rot = 8u * ((uint32_t)r & 3u);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
@@ -906,8 +926,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
                 const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
                 float pd = pv, dpe = dp[reg];
                 if (DROP) {
-                    const uint64_t di = (uint64_t)(((b * a.H + head) * a.Lq + (qq < a.Lq ? qq : a.Lq - 1)) * drop_ldk(a.Lk) + krow);
-                    const bool keep = drop_keep(a.drop, di);
+                    const uint32_t hv = (reg & 3) == 0 ? quad_bcast<0>(hq[reg >> 2])
+                                      : (reg & 3) == 1 ? quad_bcast<1>(hq[reg >> 2])
+                                      : (reg & 3) == 2 ? quad_bcast<2>(hq[reg >> 2]) : quad_bcast<3>(hq[reg >> 2]);
+                    const bool keep = rotr32(hv, rot) >= a.drop.thr;
                     pd = keep ? pv * a.drop.inv_keep : 0.f;    // the P that multiplied V in the forward pass
                     dpe = keep ? dpe * a.drop.inv_keep : 0.f;  // dP wrt the un-dropped P
                 }
