@@ -211,6 +211,27 @@ int m3ae_gather_rows(const void* in, const int64_t* idx, void* out, int64_t n_ou
 int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void* d_in, int64_t n_out, int64_t D, int dtype,
                           void* stream);
 
+/* Masked-image-modelling bookkeeping of pre-training.
+ * m3ae_mask_ranks: M3AETransformerSS.random_masking's index work (m3ae_module.py:153-183) for a given noise [B, L]
+ *   (fp32): ids_restore[b][j] = rank of patch j (= argsort(argsort(noise)), ties by index); mask[b][j] = 1 for removed
+ *   patches (rank >= len_keep); keep_rows [B, len_keep + 1]: flat row ids into the [B * (L + 1)] token rows, class row
+ *   first, then the kept patches in rank order (the gather of :176-180).
+ * m3ae_mim_targets: patchify (m3ae_module.py:185-192) of img [B, C, H, W] fp32 into out [B, (H/P)(W/P), P*P*C] fp32,
+ *   element order (p, q, c); norm_pix != 0 standardises every patch with the unbiased variance + 1e-6
+ *   (objectives.py:52-56).
+ * m3ae_mim_loss_fwd / _bwd: objectives.py:58-62 on the decoder output x [B, L + 1, D] (class row skipped,
+ *   prediction_heads.py:86), target [B, L, D] fp32, mask [B, L] fp32: loss[0] = sum_n mask mean_d (x - t)^2 / sum mask.
+ *   acc: fp32[2] scratch owned by the caller, written by fwd (masked error sum, mask sum) and read by bwd;
+ *   gout: fp32[1] device scalar (upstream gradient); dx [B, L + 1, D] (class rows zero). */
+int m3ae_mask_ranks(const float* noise, int64_t* ids_restore, int64_t* keep_rows, float* mask, int64_t B, int64_t L,
+                    int64_t len_keep, void* stream);
+int m3ae_mim_targets(const float* img, float* out, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int norm_pix,
+                     void* stream);
+int m3ae_mim_loss_fwd(const void* x, const float* target, const float* mask, float* acc, float* loss, int64_t B, int64_t L,
+                      int64_t D, int dtype, void* stream);
+int m3ae_mim_loss_bwd(const void* x, const float* target, const float* mask, const float* acc, const float* gout, void* dx,
+                      int64_t B, int64_t L, int64_t D, int dtype, void* stream);
+
 /* tuning knobs for A/B measurements (process-global, not part of the data path contract).
  * key 0: NT GEMM kernel (-1 = auto by shape; 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its
  *        persistent form, 9 = dual kernel: 128x256 tiles, two workgroups per CU);

@@ -542,3 +542,136 @@ extern "C" int m3ae_scatter_add_rows(const void* d_out, const int64_t* idx, void
     DT_SWITCH(dtype, hipLaunchKernelGGL(scatter_add_rows_kernel<T>, dim3(ew_grid(n_out * D)), dim3(EW_BLOCK), 0, s, (const T*)d_out, idx, (T*)d_in, n_out, D));
     return hip_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Masked-image-modelling bookkeeping (pre-training): random_masking's index work, the MIM target and
+// the masked mean-squared error with its gradient.
+// ---------------------------------------------------------------------------------------------------------
+// m3ae_module.py:153-183: ids_shuffle = argsort(noise), ids_restore = argsort(ids_shuffle) = the RANK of every patch;
+// kept patches = ranks < len_keep.  One workgroup per sample, the noise row in LDS, rank by counting
+// (value, index) pairs in order -- L^2 comparisons (576^2 per sample) instead of a sort; ties break by index (a stable
+// argsort).  keep_rows: flat row ids into [B * (L + 1)] token rows, the class row first (m3ae_module.py:176-180).
+namespace {
+__global__ void mask_ranks_kernel(const float* __restrict__ noise, int64_t* __restrict__ ids_restore,
+                                  int64_t* __restrict__ keep_rows, float* __restrict__ mask, int L, int len_keep) {
+    extern __shared__ float row[];
+    const int64_t b = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) row[i] = noise[b * L + i];
+    __syncthreads();
+    if (threadIdx.x == 0) keep_rows[b * (len_keep + 1)] = b * (L + 1);
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        const float v = row[j];
+        int rank = 0;
+        for (int i = 0; i < L; ++i) {
+            const float u = row[i];
+            rank += (u < v || (u == v && i < j)) ? 1 : 0;
+        }
+        ids_restore[b * L + j] = rank;
+        mask[b * L + j] = rank >= len_keep ? 1.0f : 0.0f;
+        if (rank < len_keep) keep_rows[b * (len_keep + 1) + 1 + rank] = b * (L + 1) + 1 + j;
+    }
+}
+
+// m3ae_module.py:185-192 (einsum nchpwq->nhwpqc) + objectives.py:52-56: one wave per patch; element (p, q, c) of patch
+// (h, w) is img[n][c][h P + p][w P + q]; with norm_pix the patch is standardised with the UNBIASED variance + 1e-6.
+__global__ void mim_targets_kernel(const float* __restrict__ img, float* __restrict__ out, int64_t n_patches, int C,
+                                   int H, int W, int P, int norm_pix) {
+    const int64_t patch = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (patch >= n_patches) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = W / P, gh = H / P;
+    const int64_t n = patch / (gh * gw);
+    const int hw = (int)(patch % (gh * gw)), ph = hw / gw, pw = hw % gw;
+    const int D = P * P * C;
+    const float* base = img + n * (int64_t)C * H * W;
+    auto at = [&](int e) {  // e = (p * P + q) * C + c
+        const int c = e % C, pq = e / C, p = pq / P, q = pq % P;
+        return base[((int64_t)c * H + ph * P + p) * W + pw * P + q];
+    };
+    float sum = 0.f;
+    for (int e = lane; e < D; e += 64) sum += at(e);
+    const float mean = wave_sum(sum) / (float)D;
+    float ss = 0.f;
+    for (int e = lane; e < D; e += 64) { const float d = at(e) - mean; ss += d * d; }
+    const float var = wave_sum(ss) / (float)(D - 1);
+    const float rstd = 1.0f / sqrtf(var + 1.e-6f);
+    float* o = out + patch * D;
+    for (int e = lane; e < D; e += 64) o[e] = norm_pix ? (at(e) - mean) * rstd : at(e);
+}
+
+// objectives.py:58-62: loss = sum_n mask[n] mean_d (x[n][d] - t[n][d])^2 / sum_n mask[n].  x is the decoder output WITH its
+// class row ([B, L + 1, D], row 0 of every sample skipped: prediction_heads.py:86), t / mask are [B, L, ...].
+// acc[0] += masked per-patch errors, acc[1] += mask (fp32 atomics, one per wave).
+template <typename T>
+__global__ void mim_loss_fwd_kernel(const T* __restrict__ x, const float* __restrict__ t, const float* __restrict__ mask,
+                                    float* __restrict__ acc, int64_t N, int L, int D) {
+    const int64_t n = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float m = mask[n];
+    if (m == 0.f) return;
+    const T* xr = x + ((n / L) * (L + 1) + 1 + n % L) * (int64_t)D;
+    const float* tr = t + n * (int64_t)D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float e = Elem<T>::ld(xr + d) - tr[d]; ss += e * e; }
+    ss = wave_sum(ss);
+    if (lane == 0) { atomicAdd(acc, m * ss / (float)D); atomicAdd(acc + 1, m); }
+}
+__global__ void mim_loss_finalize_kernel(const float* __restrict__ acc, float* __restrict__ loss) { loss[0] = acc[0] / acc[1]; }
+// dx[b][0][:] = 0 ;  dx[b][1 + l][d] = gout * 2 (x - t) mask / (D * sum mask)
+template <typename T>
+__global__ void mim_loss_bwd_kernel(const T* __restrict__ x, const float* __restrict__ t, const float* __restrict__ mask,
+                                    const float* __restrict__ acc, const float* __restrict__ gout, T* __restrict__ dx,
+                                    int64_t rows, int L, int D) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // row of [B * (L + 1)]
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = r / (L + 1);
+    const int l = (int)(r % (L + 1)) - 1;
+    T* dr = dx + r * (int64_t)D;
+    const float m = l < 0 ? 0.f : mask[b * L + l];
+    if (m == 0.f) {
+        for (int d = lane; d < D; d += 64) Elem<T>::st(dr + d, 0.f);
+        return;
+    }
+    const float k = gout[0] * 2.0f * m / ((float)D * acc[1]);
+    const T* xr = x + r * (int64_t)D;
+    const float* tr = t + (b * L + l) * (int64_t)D;
+    for (int d = lane; d < D; d += 64) Elem<T>::st(dr + d, k * (Elem<T>::ld(xr + d) - tr[d]));
+}
+}  // namespace
+
+extern "C" int m3ae_mask_ranks(const float* noise, int64_t* ids_restore, int64_t* keep_rows, float* mask, int64_t B,
+                               int64_t L, int64_t len_keep, void* stream) {
+    if (!noise || !ids_restore || !keep_rows || !mask || B <= 0 || L <= 0 || len_keep < 0 || len_keep > L) return M3AE_ERR_ARG;
+    if (L > 16384) return M3AE_ERR_UNSUPPORTED;   // the noise row lives in LDS
+    hipLaunchKernelGGL(mask_ranks_kernel, dim3((unsigned)B), dim3(256), (size_t)L * 4, (hipStream_t)stream, noise,
+                       ids_restore, keep_rows, mask, (int)L, (int)len_keep);
+    return hip_launch_status();
+}
+extern "C" int m3ae_mim_targets(const float* img, float* out, int64_t B, int64_t C, int64_t H, int64_t W, int64_t P,
+                                int norm_pix, void* stream) {
+    if (!img || !out || B <= 0 || C <= 0 || P <= 0 || H <= 0 || W <= 0 || H % P || W % P || P * P * C < 2) return M3AE_ERR_ARG;
+    const int64_t n = B * (H / P) * (W / P);
+    hipLaunchKernelGGL(mim_targets_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, img, out, n,
+                       (int)C, (int)H, (int)W, (int)P, norm_pix);
+    return hip_launch_status();
+}
+extern "C" int m3ae_mim_loss_fwd(const void* x, const float* target, const float* mask, float* acc, float* loss, int64_t B,
+                                 int64_t L, int64_t D, int dtype, void* stream) {
+    if (!x || !target || !mask || !acc || !loss || B <= 0 || L <= 0 || D <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    { const hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), s); if (e != hipSuccess) return (int)e; }
+    DT_SWITCH(dtype, hipLaunchKernelGGL(mim_loss_fwd_kernel<T>, dim3((unsigned)cdiv(B * L, 4)), dim3(256), 0, s, (const T*)x,
+                                        target, mask, acc, B * L, (int)L, (int)D));
+    hipLaunchKernelGGL(mim_loss_finalize_kernel, dim3(1), dim3(1), 0, s, acc, loss);
+    return hip_launch_status();
+}
+extern "C" int m3ae_mim_loss_bwd(const void* x, const float* target, const float* mask, const float* acc, const float* gout,
+                                 void* dx, int64_t B, int64_t L, int64_t D, int dtype, void* stream) {
+    if (!x || !target || !mask || !acc || !gout || !dx || B <= 0 || L <= 0 || D <= 0) return M3AE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    DT_SWITCH(dtype, hipLaunchKernelGGL(mim_loss_bwd_kernel<T>, dim3((unsigned)cdiv(B * (L + 1), 4)), dim3(256), 0, s,
+                                        (const T*)x, target, mask, acc, gout, (T*)dx, B * (L + 1), (int)L, (int)D));
+    return hip_launch_status();
+}

@@ -68,6 +68,10 @@ _SIGS = {
     "m3ae_act_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, vp]),
     "m3ae_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
     "m3ae_scatter_add_rows": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, vp]),
+    "m3ae_mask_ranks": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "m3ae_mim_targets": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_int, vp]),
+    "m3ae_mim_loss_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
+    "m3ae_mim_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_selftest": (C.c_int, [vp, vp]),
     "m3ae_set_tuning": (C.c_int, [C.c_int, C.c_int]),
 }

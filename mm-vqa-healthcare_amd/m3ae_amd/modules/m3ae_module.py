@@ -136,33 +136,22 @@ class M3AETransformerSS(_Base):
 
     # ------------------------------------------------------------------------------------------------------
     def random_masking(self, x, mask_ratio, noise=None):
-        """m3ae_module.py:153-183.  Index bookkeeping (argsort of the noise) is integer glue; the row gather and
-        its gradient run in the library."""
+        """m3ae_module.py:153-183.  The argsort / argsort-of-argsort / gather-of-ones bookkeeping is one kernel
+        (`m3ae_mask_ranks`: ranks by counting); the row gather and its gradient run in the library too."""
         B, Lp1, D = x.shape
         L = Lp1 - 1
         len_keep = int(L * (1 - mask_ratio))
         if noise is None:
             noise = torch.rand(B, L, device=x.device)
-        ids_shuffle = torch.argsort(noise, dim=1)
-        ids_restore = torch.argsort(ids_shuffle, dim=1)
-        ids_keep = ids_shuffle[:, :len_keep]
+        ids_restore, keep_rows, mask = ops.mask_ranks(noise, len_keep)
         pos = self.vision_encoder.visual.positional_embedding
         xp = x + pos.to(x.dtype)  # x + pos, cls row included (m3ae_module.py:169,180); pretrain-only glue
-        flat_idx = torch.cat([torch.zeros(B, 1, dtype=torch.long, device=x.device), ids_keep + 1], dim=1)
-        flat_idx = (flat_idx + torch.arange(B, device=x.device).view(B, 1) * Lp1).reshape(-1)
-        x_masked = ops.gather_rows(xp, flat_idx).view(B, len_keep + 1, D)
-        mask = torch.ones(B, L, device=x.device)
-        mask[:, :len_keep] = 0
-        mask = torch.gather(mask, dim=1, index=ids_restore)
+        x_masked = ops.gather_rows(xp, keep_rows).view(B, len_keep + 1, D)
         return x_masked, mask, ids_restore
 
     def patchify(self, imgs):
-        """m3ae_module.py:185-192."""
-        p = self.hparams.config["patch_size"]
-        h = w = imgs.shape[2] // p
-        x = imgs.reshape(imgs.shape[0], 3, h, p, w, p)
-        x = torch.einsum("nchpwq->nhwpqc", x)
-        return x.reshape(imgs.shape[0], h * w, p ** 2 * 3)
+        """m3ae_module.py:185-192 (`m3ae_mim_targets` without the standardisation)."""
+        return ops.mim_targets(imgs, self.hparams.config["patch_size"], False)
 
     def infer(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, img=None,
               output_attentions=False, unimodal=False):

@@ -47,15 +47,11 @@ def compute_mlm(pl_module, batch):
     return {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
 
 
-def mim_targets(pl_module, patched_images):
-    """objectives.py:52-56: per-patch normalisation with the UNBIASED variance (torch.var default) + 1e-6.
-    A function of the input image only (no parameters, no gradient): fp32 host-side-style glue."""
-    target = patched_images.float()
-    if pl_module.hparams.config["norm_pix_loss"]:
-        mean = target.mean(dim=-1, keepdim=True)
-        var = target.var(dim=-1, keepdim=True)
-        target = (target - mean) / (var + 1.e-6) ** .5
-    return target
+def mim_targets(pl_module, images):
+    """objectives.py:52-56 from the IMAGE (patchify + per-patch standardisation with the unbiased variance + 1e-6 in one
+    kernel); a function of the input only (no parameters, no gradient)."""
+    cfg = pl_module.hparams.config
+    return ops.mim_targets(images, cfg["patch_size"], cfg["norm_pix_loss"])
 
 
 def compute_mim(pl_module, batch):
@@ -63,12 +59,10 @@ def compute_mim(pl_module, batch):
     infer = pl_module.infer(batch, mask_text=False, mask_image=True)
     layer_idx = pl_module.hparams.config["mim_layer"]
     feats = infer["multi_modal_image_feats"] if layer_idx == -1 else infer[f"multi_modal_image_feats_{layer_idx}"]
-    mim_logits = pl_module.mim_head(feats, infer["mim_ids_restore"])
-    target = mim_targets(pl_module, infer["patched_images"])
-    mask = infer["mim_masks"]
-    per_patch = ((mim_logits.float() - target) ** 2).mean(dim=-1)
-    mim_loss = (per_patch * mask).sum() / mask.sum()
-    return {"mim_loss": mim_loss, "mim_logits": mim_logits, "mim_labels": target}
+    full = pl_module.mim_head(feats, infer["mim_ids_restore"], keep_cls=True)   # [B, L + 1, D]
+    target = mim_targets(pl_module, batch["image_0" if "image_0" in batch else "image"][0])   # the image infer() used
+    mim_loss = ops.mim_loss(full, target, infer["mim_masks"])   # masked per-patch MSE, class row skipped inside
+    return {"mim_loss": mim_loss, "mim_logits": full[:, 1:, :], "mim_labels": target}
 
 
 def compute_itm(pl_module, batch, itm_labels=None):

@@ -85,7 +85,7 @@ class MIMHead(nn.Module):
         self.decoder_norm = LayerNorm(dh)
         self.decoder_pred = nn.Linear(dh, self.patch_size ** 2 * 3, bias=True)
 
-    def forward(self, x, ids_restore):
+    def forward(self, x, ids_restore, keep_cls=False):
         B, Lk, _ = x.shape
         x = ops.linear(x, self.decoder_embed.weight, self.decoder_embed.bias)
         dh = x.shape[-1]
@@ -99,7 +99,7 @@ class MIMHead(nn.Module):
         x = self.decoder(x.contiguous())
         x = ops.layer_norm(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
         x = ops.linear(x, self.decoder_pred.weight, self.decoder_pred.bias)
-        return x[:, 1:, :]
+        return x if keep_cls else x[:, 1:, :]   # prediction_heads.py:86 drops the class row; the loss kernel skips it itself
 
     def weight_units(self):
         return [self.decoder_embed.weight, self.decoder_pred.weight] + self.decoder.weight_units()

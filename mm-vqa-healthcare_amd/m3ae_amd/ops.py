@@ -1188,3 +1188,61 @@ def selftest():
     out = torch.zeros(8 + 256, dtype=torch.int32, device="cuda")
     check(_lib.lib().m3ae_selftest(_p(out), _stream()), "m3ae_selftest")
     return out[:6].cpu().tolist()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# masked-image-modelling bookkeeping (pre-training)
+# ------------------------------------------------------------------------------------------------------------
+def mask_ranks(noise, len_keep):
+    """random_masking's index work (m3ae_module.py:153-183) -> ids_restore [B, L] int64, keep_rows [B * (len_keep + 1)]
+    int64 (flat token-row ids, class row first), mask [B, L] fp32 (1 = removed)."""
+    _need_cuda(noise)
+    B, L = noise.shape
+    n = noise.contiguous().float()
+    ids_restore = torch.empty((B, L), dtype=torch.long, device=noise.device)
+    keep_rows = torch.empty((B, len_keep + 1), dtype=torch.long, device=noise.device)
+    mask = torch.empty((B, L), dtype=torch.float32, device=noise.device)
+    check(_lib.lib().m3ae_mask_ranks(_p(n), _p(ids_restore), _p(keep_rows), _p(mask), B, L, len_keep, _stream()),
+          "m3ae_mask_ranks")
+    return ids_restore, keep_rows.view(-1), mask
+
+
+def mim_targets(img, patch, norm_pix):
+    """patchify (m3ae_module.py:185-192) [+ per-patch standardisation, objectives.py:52-56]: [B, C, H, W] -> [B, L, P*P*C]."""
+    _need_cuda(img)
+    B, Cc, H, W = img.shape
+    x = img.contiguous().float()
+    out = torch.empty((B, (H // patch) * (W // patch), patch * patch * Cc), dtype=torch.float32, device=img.device)
+    check(_lib.lib().m3ae_mim_targets(_p(x), _p(out), B, Cc, H, W, patch, int(bool(norm_pix)), _stream()), "m3ae_mim_targets")
+    return out
+
+
+class MimLossFn(torch.autograd.Function):
+    """objectives.py:58-62 on the decoder output WITH its class row (x [B, L + 1, D]): masked per-patch MSE."""
+
+    @staticmethod
+    def forward(ctx, x, target, mask):
+        _need_cuda(x)
+        xc = x.contiguous()
+        B, L1, D = xc.shape
+        t, m = target.contiguous().float(), mask.contiguous().float()
+        acc = torch.empty(2, dtype=torch.float32, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        check(_lib.lib().m3ae_mim_loss_fwd(_p(xc), _p(t), _p(m), _p(acc), _p(loss), B, L1 - 1, D, _dt(xc), _stream()),
+              "m3ae_mim_loss_fwd")
+        ctx.save_for_backward(xc, t, m, acc)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, t, m, acc = ctx.saved_tensors
+        B, L1, D = xc.shape
+        dx = torch.empty_like(xc)
+        go = g.detach().reshape(1).float().contiguous()
+        check(_lib.lib().m3ae_mim_loss_bwd(_p(xc), _p(t), _p(m), _p(acc), _p(go), _p(dx), B, L1 - 1, D, _dt(xc), _stream()),
+              "m3ae_mim_loss_bwd")
+        return dx, None, None
+
+
+def mim_loss(x_with_cls, target, mask):
+    return MimLossFn.apply(x_with_cls, target, mask)

@@ -617,3 +617,43 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
                 assert torch.equal(outs[v][1].view(torch.int16), outs[4][1].view(torch.int16)), (kind, v, "derivative")
     finally:
         L.m3ae_set_tuning(0, -1)
+
+
+def test_mim_bookkeeping_kernels_match_the_reference_formulas():
+    """random_masking's index work (m3ae_module.py:153-183), the MIM target (patchify :185-192 +
+    objectives.py:52-56) and the masked MSE with its gradient (objectives.py:58-62) against the reference's own torch
+    expressions, evaluated on the CPU in fp32.  Index outputs exact; ties in the noise included."""
+    g = torch.Generator().manual_seed(3)
+    B, L, keep = 5, 36, 9
+    noise = torch.rand(B, L, generator=g)
+    noise[1, 7] = noise[1, 3]                          # a tie: ranks follow the index order (stable argsort)
+    ids_restore, keep_rows, mask = ops.mask_ranks(noise.to(dev()), keep)
+    shuf = torch.argsort(noise, dim=1, stable=True)
+    restore = torch.argsort(shuf, dim=1)
+    ref_mask = torch.ones(B, L)
+    ref_mask[:, :keep] = 0
+    ref_mask = torch.gather(ref_mask, 1, restore)
+    assert torch.equal(ids_restore.cpu(), restore) and torch.equal(mask.cpu(), ref_mask)
+    ref_rows = torch.cat([torch.zeros(B, 1, dtype=torch.long), shuf[:, :keep] + 1], 1) + torch.arange(B).view(B, 1) * (L + 1)
+    assert torch.equal(keep_rows.cpu().view(B, keep + 1), ref_rows)
+
+    P, C, H = 4, 3, 24
+    img = torch.randn(B, C, H, H, generator=g)
+    x = img.reshape(B, C, H // P, P, H // P, P)
+    pat = torch.einsum("nchpwq->nhwpqc", x).reshape(B, (H // P) ** 2, P * P * C)
+    assert torch.equal(ops.mim_targets(img.to(dev()), P, False).cpu(), pat)
+    tgt = (pat - pat.mean(-1, keepdim=True)) / (pat.var(-1, keepdim=True) + 1.e-6) ** .5
+    close(ops.mim_targets(img.to(dev()), P, True), tgt, 1e-5, 1e-5, "norm-pix target")
+
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        full = torch.randn(B, L + 1, P * P * C, generator=g).to(dtype)
+        xr = full.float().clone().requires_grad_(True)
+        per = ((xr[:, 1:, :] - tgt) ** 2).mean(-1)
+        ref = (per * ref_mask).sum() / ref_mask.sum()
+        (3.0 * ref).backward()
+        xd = full.to(dev()).requires_grad_(True)
+        loss = ops.mim_loss(xd, tgt.to(dev()), mask)
+        (3.0 * loss).backward()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-6
+        close(xd.grad, xr.grad, tol, 1e-7, f"mim dlogits {dtype}")
+        assert float(xd.grad[:, 0].abs().max()) == 0.0
