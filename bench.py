@@ -213,7 +213,9 @@ def main():
         if dom in agg:
             n, ms, fl = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_persistent_kernel", "achieved": round(ach, 1),
+            # data-parallel runs use the one-tile-per-workgroup launch of the same kernel body (ddp.FlatGradReducer.attach)
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_persistent_kernel" if world == 1 else "gemm_nt_pp_kernel",
+                        "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": None, "launches": n // 2, "avg_launch_ms": round(ms / n, 4),
                         "flops_per_launch": fl / n}

@@ -659,3 +659,32 @@ def test_grad_reducer_over_rccl_single_rank_group():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+def test_bench_line_contract():
+    """bench.py as the driver runs it (a child process, defaults except a smaller batch and fewer steps): exactly one JSON
+    line with the contract's keys, the roofline object of the dominant kernel measured live, finite positive numbers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["per_gpu_batch"] == 64 and d["config"]["global_batch"] == 64
+    assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert 0 < r["achieved"] < r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert d["cpu_baseline"] is None          # switched off above; the default run carries it
+    x = d["cross_attention_fwd"]
+    assert x["batch"] == 64 and 0 < x["frac"] < 1
