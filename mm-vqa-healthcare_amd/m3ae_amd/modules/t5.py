@@ -173,6 +173,32 @@ class T5Stack(nn.Module):
         ln = self.final_layer_norm
         return ops.dropout(ops.layer_norm(h, ln.weight, None, ln.eps, rms=True), self.dropout_rate, self.training)
 
+    @torch.no_grad()
+    def cross_kv(self, enc):
+        """Decoder only: keys / values of the encoder output for every block's cross-attention ([B * Ls, 2 inner] each),
+        computed ONCE per generation instead of at every decoding step (the reference's third-party `generate` keeps them
+        in `past_key_values`)."""
+        B, Ls, De = enc.shape
+        enc2 = enc.contiguous().view(B * Ls, De)
+        return [ops.mm_nt(enc2, De, B * Ls, ops.compute_weight(blk.params().cross.w_kv))[0] for blk in self.block]
+
+    @torch.no_grad()
+    def forward_cached(self, h, cross_kv, Ls):
+        """Decoder only, inference: the blocks' own kernels in the blocks' own order (ops.T5DecBlockFn.forward), with the
+        cross-attention keys / values taken from `cross_kv`."""
+        B, T, D = h.shape
+        pd = self.dropout_rate if self.training else 0.0
+        h = ops.dropout(h, self.dropout_rate, self.training)
+        bias = self.block[0].layer[0].SelfAttention.position_bias(T, T).detach()
+        h2 = h.contiguous().view(B * T, D)
+        for blk, kv in zip(self.block, cross_kv):
+            P = blk.params()
+            a, _ = ops._t5_attn_fwd(h2, B, T, None, T, P.attn, bias, True, pd)
+            c, _ = ops._t5_attn_fwd(a, B, T, None, Ls, P.cross, None, False, pd, kv=kv)
+            h2, _ = ops._t5_ff_fwd(c, P.ffn, pd)
+        ln = self.final_layer_norm
+        return ops.dropout(ops.layer_norm(h2.view(B, T, D), ln.weight, None, ln.eps, rms=True), self.dropout_rate, self.training)
+
     def weight_units(self):
         u = []
         for b in self.block:
@@ -211,9 +237,13 @@ class T5ForConditionalGeneration(nn.Module):
         return ops.EmbedRowsFn.apply(ids.reshape(-1), w, table).view(B, T, -1)
 
     @torch.no_grad()
-    def next_token_logits(self, enc, prefix):
-        """Decoder over the whole prefix (no KV cache yet: T <= 12 here) -> logits of the last position, fp32."""
-        dec = self.decoder(self.embed(prefix, enc.dtype), enc)
+    def next_token_logits(self, enc, prefix, cross_kv=None):
+        """Decoder over the whole prefix (T <= 12 here: the self-attention keys are recomputed, the 512-token encoder
+        side comes from `cross_kv` when given) -> logits of the last position, fp32."""
+        if cross_kv is not None:
+            dec = self.decoder.forward_cached(self.embed(prefix, enc.dtype), cross_kv, enc.shape[1])
+        else:
+            dec = self.decoder(self.embed(prefix, enc.dtype), enc)
         last = dec[:, -1].contiguous()
         return ops.linear(last, self.shared.weight, None, alpha=self.config.d_model ** -0.5).float()
 
@@ -228,6 +258,10 @@ class T5ForConditionalGeneration(nn.Module):
         host logic on one small device->host copy per step."""
         B, nb, dev = enc.shape[0], num_beams, enc.device
         enc_r = enc.repeat_interleave(nb, dim=0).contiguous()
+        # encoder-side keys / values once per call; the beams of a sample share their encoder rows, so re-ordering beams
+        # never touches this cache
+        Ls = enc.shape[1]
+        cross_kv = [kv.view(B, Ls, -1).repeat_interleave(nb, dim=0).reshape(B * nb * Ls, -1) for kv in self.decoder.cross_kv(enc)]
         ids = torch.full((B * nb, 1), self.config.decoder_start_token_id, dtype=torch.long, device=dev)
         beam_scores = torch.zeros(B, nb, device=dev)
         beam_scores[:, 1:] = -1e9
@@ -236,7 +270,7 @@ class T5ForConditionalGeneration(nn.Module):
         done = [False] * B
         cur_len = 1
         while cur_len < max_length:
-            logp = torch.log_softmax(self.next_token_logits(enc_r, ids), dim=-1)
+            logp = torch.log_softmax(self.next_token_logits(enc_r, ids, cross_kv), dim=-1)
             V = logp.shape[-1]
             top_s, top_i = torch.topk((logp + beam_scores[:, None]).view(B, nb * V), 2 * nb, dim=1)
             top_s, top_i = top_s.cpu(), top_i.cpu()

@@ -755,14 +755,15 @@ def _drop_raw(x2, drop):
     return out
 
 
-def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal, pdrop=0.0):
+def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal, pdrop=0.0, kv=None):
+    # kv: the projected keys / values of `src2` computed earlier ([B * Ls, 2 inner]; generation re-uses them every step)
     # HF T5 (third party, transformers 4.6.0): attention-weight dropout inside T5Attention and `hidden + dropout(attn)`
     da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     n, _, rstd = ln_fwd_raw(h2, P.ln, rms=True)
     D = n.shape[1]
     inner = P.w_o.shape[1]
-    if src2 is None:
+    if src2 is None and kv is None:
         qkv, _ = mm_nt(n, D, B * L, compute_weight(P.w_qkv))
         v3 = qkv.view(B, L, 3 * inner)
         o, lse = attn_forward(v3[..., :inner], v3[..., inner:2 * inner], v3[..., 2 * inner:], P.heads, None, bias,
@@ -770,7 +771,8 @@ def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal, pdrop=0.0):
         proj = (qkv,)
     else:
         q, _ = mm_nt(n, D, B * L, compute_weight(P.w_q))
-        kv, _ = mm_nt(src2, src2.shape[1], B * Ls, compute_weight(P.w_kv))
+        if kv is None:
+            kv, _ = mm_nt(src2, src2.shape[1], B * Ls, compute_weight(P.w_kv))
         kv3 = kv.view(B, Ls, 2 * inner)
         o, lse = attn_forward(q.view(B, L, inner), kv3[..., :inner], kv3[..., inner:], P.heads, None, bias, scale=1.0,
                               causal=causal, dropout=da)

@@ -416,6 +416,11 @@ def test_t5_generate_matches_oracle_and_third_party(len_offset):
     m.eval()
     enc = torch.from_numpy(g["enc"]).cuda()
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    # the encoder-side key / value cache of generate(): same logits, bit for bit, as the decoder run on `enc` itself
+    prefix = torch.tensor([[0, 5, 9, 700]] * enc.shape[0], device="cuda")
+    kv = m.decoder.cross_kv(enc)
+    assert len(kv) == 2 and kv[0].shape == (enc.shape[0] * enc.shape[1], 2 * 8 * 64)
+    assert torch.equal(m.next_token_logits(enc, prefix), m.next_token_logits(enc, prefix, kv))
     for eos in g["eos_ids"].tolist():
         mine = m.generate(enc, num_beams=4, max_length=8, eos_token_id=eos, len_offset=len_offset)
         with torch.no_grad():
