@@ -19,6 +19,21 @@ template <> DEVINL void ld4<bf16_t>(const bf16_t* p, float* x) {
     x[0] = __uint_as_float(v[0] << 16); x[1] = __uint_as_float(v[0] & 0xffff0000u);
     x[2] = __uint_as_float(v[1] << 16); x[3] = __uint_as_float(v[1] & 0xffff0000u);
 }
+// raw (unconverted) 4-element chunk: a load can be issued a row ahead and unpacked when it is used
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    f32x4 v;
+    DEVINL void ld(const float* p) { v = *(const f32x4*)p; }
+    DEVINL void get(float* x) const { x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3]; }
+};
+template <> struct Raw4<bf16_t> {
+    u32x2 v;
+    DEVINL void ld(const bf16_t* p) { v = *(const u32x2*)p; }
+    DEVINL void get(float* x) const {
+        x[0] = __uint_as_float(v[0] << 16); x[1] = __uint_as_float(v[0] & 0xffff0000u);
+        x[2] = __uint_as_float(v[1] << 16); x[3] = __uint_as_float(v[1] & 0xffff0000u);
+    }
+};
 template <typename T> DEVINL void st4(T* p, const float* x);
 template <> DEVINL void st4<float>(float* p, const float* x) { *(f32x4*)p = (f32x4){x[0], x[1], x[2], x[3]}; }
 template <> DEVINL void st4<bf16_t>(bf16_t* p, const float* x) {
@@ -30,57 +45,76 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
                                                      float* mean_o, float* rstd_o, int64_t M, int D, float eps,
                                                      int act, int rms) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int nch = D >> 2;
-    const T* xr = x + row * D;
-    float v[CPL][4];
-    float sum = 0.f;
+    // grid-stride over rows (the grid is what fits on the chip at once): the next row is requested as soon as the current
+    // one is unpacked, so its HBM latency runs under this row's two reductions, the output arithmetic and the stores
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    Raw4<T> raw[CPL];
+    if (row < M) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nch) {
-            ld4<T>(xr + ch * 4, v[c]);
-            sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-        } else {
-            v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) raw[c].ld(x + row * D + ch * 4);
         }
     }
-    const float mean = rms ? 0.f : wave_sum(sum) / (float)D;
-    float sq = 0.f;
+    for (; row < M; row += stride) {
+        float v[CPL][4];
+        float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nch) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float dlt = v[c][t] - mean;
-                sq += dlt * dlt;
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                raw[c].get(v[c]);
+                sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+            } else {
+                v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
             }
         }
-    }
-    const float var = wave_sum(sq) / (float)D;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (lane == 0) {
-        if (mean_o) mean_o[row] = mean;
-        if (rstd_o) rstd_o[row] = rstd;
-    }
-    T* yr = y + row * D;
+        const int64_t nrow = row + stride;
+        if (nrow < M) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nch) {
-            float g[4], b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-            ld4<float>(gamma + ch * 4, g);
-            if (beta) ld4<float>(beta + ch * 4, b);
+            for (int c = 0; c < CPL; ++c) {
+                const int ch = lane + c * 64;
+                if (ch < nch) raw[c].ld(x + nrow * D + ch * 4);
+            }
+        }
+        const float mean = rms ? 0.f : wave_sum(sum) / (float)D;
+        float sq = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = act_fwd((v[c][t] - mean) * rstd * g[t] + b[t], act);
-            st4<T>(yr + ch * 4, o);
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float dlt = v[c][t] - mean;
+                    sq += dlt * dlt;
+                }
+            }
+        }
+        const float var = wave_sum(sq) / (float)D;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (lane == 0) {
+            if (mean_o) mean_o[row] = mean;
+            if (rstd_o) rstd_o[row] = rstd;
+        }
+        T* yr = y + row * D;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) {
+                float g[4], b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+                ld4<float>(gamma + ch * 4, g);
+                if (beta) ld4<float>(beta + ch * 4, b);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = act_fwd((v[c][t] - mean) * rstd * g[t] + b[t], act);
+                st4<T>(yr + ch * 4, o);
+            }
         }
     }
 }
 
-template <typename T, int CPL>
+template <typename T, int CPL, bool ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* beta,
                                                      const float* mean_i, const float* rstd_i, T* dx, const T* dx_add,
                                                      float* part, int64_t M, int D, int act, int rms, T* dx_drop,
@@ -88,20 +122,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
     extern __shared__ float red[];  // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    float dg[CPL][4], db[CPL][4], g[CPL][4], bt[CPL][4];
+    // ACT (LayerNorm + activation fused in the forward: the vqa_head) is the only case that needs beta here; the plain
+    // instantiation stays at 4 waves / SIMD with the next row's raw registers added
+    float dg[CPL][4], db[CPL][4], g[CPL][4], bt[ACT ? CPL : 1][4];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int ch = lane + c * 64;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { dg[c][t] = 0.f; db[c][t] = 0.f; g[c][t] = 0.f; bt[c][t] = 0.f; }
+        for (int t = 0; t < 4; ++t) { dg[c][t] = 0.f; db[c][t] = 0.f; g[c][t] = 0.f; if (ACT) bt[c][t] = 0.f; }
         if (ch < nch) {
             ld4<float>(gamma + ch * 4, g[c]);
-            if (beta) ld4<float>(beta + ch * 4, bt[c]);
+            if (ACT && beta) ld4<float>(beta + ch * 4, bt[c]);
         }
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
-        const float mean = rms ? 0.f : mean_i[row];
-        const float rstd = rstd_i[row];
+    // A wave walks its rows one after the other.  The NEXT row's x / dy (raw, packed) and statistics are requested as soon
+    // as the current row's registers have been unpacked into xh / dxh, so the two wave reductions, the output arithmetic
+    // and the stores of a row run under the next row's HBM latency.
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    Raw4<T> xr[CPL], dr[CPL];
+    float mean_n = 0.f, rstd_n = 0.f;
+    if (row < M) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nch) { xr[c].ld(x + row * D + ch * 4); dr[c].ld(dy + row * D + ch * 4); }
+        }
+        mean_n = rms ? 0.f : mean_i[row];
+        rstd_n = rstd_i[row];
+    }
+    for (; row < M; row += stride) {
+        const float mean = mean_n;
+        const float rstd = rstd_n;
         float xh[CPL][4], dxh[CPL][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -109,13 +161,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
             const int ch = lane + c * 64;
             if (ch < nch) {
                 float xv[4], dv[4];
-                ld4<T>(x + row * D + ch * 4, xv);
-                ld4<T>(dy + row * D + ch * 4, dv);
+                xr[c].get(xv);
+                dr[c].get(dv);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float h = (xv[t] - mean) * rstd;
                     float d = dv[t];
-                    if (act != M3AE_ACT_NONE) d *= act_bwd(h * g[c][t] + bt[c][t], act);
+                    if (ACT) d *= act_bwd(h * g[c][t] + bt[c][t], act);
                     dg[c][t] += d * h;
                     db[c][t] += d;
                     const float dh = d * g[c][t];
@@ -128,6 +180,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { xh[c][t] = 0.f; dxh[c][t] = 0.f; }
             }
+        }
+        const int64_t nrow = row + stride;
+        if (nrow < M) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int ch = lane + c * 64;
+                if (ch < nch) { xr[c].ld(x + nrow * D + ch * 4); dr[c].ld(dy + nrow * D + ch * 4); }
+            }
+            mean_n = rms ? 0.f : mean_i[nrow];
+            rstd_n = rstd_i[nrow];
         }
         const float c1 = rms ? 0.f : wave_sum(s1) / (float)D;
         const float c2 = wave_sum(s2) / (float)D;
@@ -203,20 +265,46 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, f
     }
 }
 
+// workgroups that can be resident at once (every wave walks its rows in a grid-stride loop: a workgroup that has to wait for
+// a free slot would start a second round with a full share of the rows)
+template <typename K> int resident_blocks(K kernel, size_t lds) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu <= 0) return 1 << 30;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1 << 30;
+    return per_cu * prop.multiProcessorCount;
+}
 template <typename T, int CPL>
 int launch_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t M, int D,
                float eps, int act, int rms, hipStream_t s) {
-    hipLaunchKernelGGL((ln_fwd_kernel<T, CPL>), dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, (const T*)x, g, b, (T*)y,
-                       mean, rstd, M, D, eps, act, rms);
+    static const int cap = resident_blocks(ln_fwd_kernel<T, CPL>, 0);
+    const int64_t want = cdiv(M, 4);
+    hipLaunchKernelGGL((ln_fwd_kernel<T, CPL>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, (const T*)x, g, b,
+                       (T*)y, mean, rstd, M, D, eps, act, rms);
     return hip_launch_status();
 }
 template <typename T, int CPL>
 int launch_bwd(const void* dy, const void* x, const float* g, const float* b, const float* mean, const float* rstd,
-               void* dx, const void* dx_add, float* part, int nblk, int64_t M, int D, int act, int rms, hipStream_t s,
+               void* dx, const void* dx_add, float* part, int* nblk_io, int64_t M, int D, int act, int rms, hipStream_t s,
                void* dx_drop = nullptr, DropState drop = DropState{}) {
-    hipLaunchKernelGGL((ln_bwd_kernel<T, CPL>), dim3((unsigned)nblk), dim3(256), (size_t)8 * D * sizeof(float), s,
-                       (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, (const T*)dx_add, part, M, D, act, rms,
-                       (T*)dx_drop, drop);
+    const size_t lds = (size_t)8 * D * sizeof(float);
+    static int cap_act = 0, cap_plain = 0, cap_d = -1;   // per instantiation; the LDS size follows D
+    if (cap_d != D) {
+        cap_act = resident_blocks(ln_bwd_kernel<T, CPL, true>, lds);
+        cap_plain = resident_blocks(ln_bwd_kernel<T, CPL, false>, lds);
+        cap_d = D;
+    }
+    const int cap = act != M3AE_ACT_NONE ? cap_act : cap_plain;
+    const int nblk = *nblk_io < cap ? *nblk_io : cap;
+    *nblk_io = nblk;
+    if (act != M3AE_ACT_NONE)
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CPL, true>), dim3((unsigned)nblk), dim3(256), lds, s,
+                           (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, (const T*)dx_add, part, M, D, act, rms,
+                           (T*)dx_drop, drop);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<T, CPL, false>), dim3((unsigned)nblk), dim3(256), lds, s,
+                           (const T*)dy, (const T*)x, g, b, mean, rstd, (T*)dx, (const T*)dx_add, part, M, D, act, rms,
+                           (T*)dx_drop, drop);
     return hip_launch_status();
 }
 
@@ -260,13 +348,13 @@ extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* ga
     if (!dy || !x || !gamma || !rstd || !dx || !workspace || M <= 0) return M3AE_ERR_ARG;
     if (D % 4 != 0 || D > 2048) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (int)m3ae_layernorm_bwd_blocks(M);
+    int nblk = (int)m3ae_layernorm_bwd_blocks(M);   // upper bound (the workspace is sized for it); launch_bwd may lower it
     int rc = M3AE_ERR_UNSUPPORTED;
     auto run = [&]() -> int {
         if (dtype == M3AE_F32)
-            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, dx_add, workspace, nblk, M, (int)D, act, rms, s);
+            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, dx_add, workspace, &nblk, M, (int)D, act, rms, s);
         if (dtype == M3AE_BF16)
-            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, dx_add, workspace, nblk, M, (int)D, act, rms, s);
+            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, dx_add, workspace, &nblk, M, (int)D, act, rms, s);
         return M3AE_ERR_UNSUPPORTED;
     };
     rc = run();
@@ -284,13 +372,13 @@ extern "C" int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const floa
     if (!dy || !x || !gamma || !rstd || !dx || !dx_drop || !workspace || M <= 0) return M3AE_ERR_ARG;
     if (D % 4 != 0 || D > 2048) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (int)m3ae_layernorm_bwd_blocks(M);
+    int nblk = (int)m3ae_layernorm_bwd_blocks(M);
     const DropState drop = make_drop(dropout_p, dropout_seed);
     auto run = [&]() -> int {
         if (dtype == M3AE_F32)
-            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, nblk, M, (int)D, 0, 0, s, dx_drop, drop);
+            DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, &nblk, M, (int)D, 0, 0, s, dx_drop, drop);
         if (dtype == M3AE_BF16)
-            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, nblk, M, (int)D, 0, 0, s, dx_drop, drop);
+            DISPATCH_CPL(launch_bwd, bf16_t, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, &nblk, M, (int)D, 0, 0, s, dx_drop, drop);
         return M3AE_ERR_UNSUPPORTED;
     };
     int rc = run();
