@@ -130,6 +130,21 @@ __global__ void patchify_kernel(const float* img, T* out, int64_t B, int64_t R, 
         Elem<T>::st(out + i, img[((b * 3 + c) * R + gy * P + py) * R + gx * P + px]);
     }
 }
+// P % 8 == 0, bf16 output: one thread moves 8 consecutive px (32 B read, 16 B written); the index is split with 32-bit
+// arithmetic (the scalar form above spends its time in seven 64-bit divisions per element: 1.3 TB/s)
+__global__ void patchify8_bf16_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, uint32_t n8, uint32_t R,
+                                      uint32_t P, uint32_t g) {
+    const uint32_t K8 = 3 * P * P / 8, P8 = P / 8;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+        const uint32_t col8 = i % K8, tok = i / K8;
+        const uint32_t px8 = col8 % P8, py = (col8 / P8) % P, c = col8 / (P8 * P);
+        const uint32_t gx = tok % g, gy = (tok / g) % g, b = tok / (g * g);
+        const float* src = img + ((int64_t)(b * 3 + c) * R + gy * P + py) * R + gx * P + px8 * 8;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+        *(u32x4*)(out + (int64_t)i * 8) = (u32x4){pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]),
+                                                  pack2bf(v1[2], v1[3])};
+    }
+}
 // NHWC uint8 -> NCHW fp32, (u / 255 - mean) / std: one thread per output pixel-channel, reads coalesced over x
 __global__ void image_normalize_u8_kernel(const uint8_t* in, float* out, int64_t B, int64_t H, int64_t W, float m0,
                                           float m1, float m2, float s0, float s1, float s2) {
@@ -150,6 +165,28 @@ __global__ void vit_tokens_fwd_kernel(const T* patch, const float* cls, const fl
         const int64_t d = i % D, l = (i / D) % L, b = i / (D * L);
         const float base = l == 0 ? cls[d] : Elem<T>::ld(patch + (b * G + l - 1) * D + d);
         Elem<T>::st(out + i, base + pos[l * D + d]);
+    }
+}
+// D % 8 == 0, bf16: 8 consecutive d per thread, 32-bit index split
+__global__ void vit_tokens_fwd8_bf16_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls,
+                                            const float* __restrict__ pos, bf16_t* __restrict__ out, uint32_t n8, uint32_t G,
+                                            uint32_t D8) {
+    const uint32_t L = G + 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+        const uint32_t d8 = i % D8, l = (i / D8) % L, b = i / (D8 * L);
+        float x[8];
+        if (l == 0) {
+            const f32x4 c0 = *(const f32x4*)(cls + d8 * 8), c1 = *(const f32x4*)(cls + d8 * 8 + 4);
+            x[0] = c0[0]; x[1] = c0[1]; x[2] = c0[2]; x[3] = c0[3]; x[4] = c1[0]; x[5] = c1[1]; x[6] = c1[2]; x[7] = c1[3];
+        } else {
+            const u32x4 v = *(const u32x4*)(patch + ((int64_t)b * G + l - 1) * (D8 * 8) + d8 * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { x[2 * t] = __uint_as_float(v[t] << 16); x[2 * t + 1] = __uint_as_float(v[t] & 0xffff0000u); }
+        }
+        const float* pr = pos + (int64_t)l * (D8 * 8) + d8 * 8;
+        const f32x4 p0 = *(const f32x4*)pr, p1 = *(const f32x4*)(pr + 4);
+        *(u32x4*)(out + (int64_t)i * 8) = (u32x4){pack2bf(x[0] + p0[0], x[1] + p0[1]), pack2bf(x[2] + p0[2], x[3] + p0[3]),
+                                                  pack2bf(x[4] + p1[0], x[5] + p1[1]), pack2bf(x[6] + p1[2], x[7] + p1[3])};
     }
 }
 // d_patch = d_out[:, 1:];  d_pos[l] += sum_b d_out[b][l];  d_cls += sum_b d_out[b][0]
@@ -401,6 +438,11 @@ extern "C" int m3ae_patchify(const float* img, void* out, int64_t B, int64_t R, 
     if (!img || !out || B <= 0 || R <= 0 || P <= 0 || R % P) return M3AE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = B * (R / P) * (R / P) * 3 * P * P;
+    if (dtype == M3AE_BF16 && P % 8 == 0 && total / 8 < (int64_t)1 << 31) {
+        hipLaunchKernelGGL(patchify8_bf16_kernel, dim3(ew_grid(total / 8)), dim3(EW_BLOCK), 0, s, img, (bf16_t*)out,
+                           (uint32_t)(total / 8), (uint32_t)R, (uint32_t)P, (uint32_t)(R / P));
+        return hip_launch_status();
+    }
     DT_SWITCH(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, img, (T*)out, B, R, P));
     return hip_launch_status();
 }
@@ -416,6 +458,12 @@ extern "C" int m3ae_vit_tokens_fwd(const void* patch, const float* cls, const fl
                                    int64_t G, int64_t D, int dtype, void* stream) {
     if (!patch || !cls || !pos || !out) return M3AE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == M3AE_BF16 && D % 8 == 0 && B * (G + 1) * D / 8 < (int64_t)1 << 31) {
+        const int64_t n8 = B * (G + 1) * D / 8;
+        hipLaunchKernelGGL(vit_tokens_fwd8_bf16_kernel, dim3(ew_grid(n8)), dim3(EW_BLOCK), 0, s, (const bf16_t*)patch, cls,
+                           pos, (bf16_t*)out, (uint32_t)n8, (uint32_t)G, (uint32_t)(D / 8));
+        return hip_launch_status();
+    }
     DT_SWITCH(dtype, hipLaunchKernelGGL(vit_tokens_fwd_kernel<T>, dim3(ew_grid(B * (G + 1) * D)), dim3(EW_BLOCK), 0, s,
                                         (const T*)patch, cls, pos, (T*)out, B, G, D));
     return hip_launch_status();
