@@ -27,7 +27,9 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;    // 32 KiB
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 64 KiB
 
 // epilogue classes (template parameter: keeps erf/exp code out of the kernels that do not need it)
-enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_QGELU = 2, EPI_DGELU = 3, EPI_DQGELU = 4, EPI_ANY = 5, EPI_DMUL = 6 };
+// EPI_RELU: the T5 feed-forward (ReLU, derivative saved, dropout after the activation); with EPI_DMUL (+ dropout) it keeps the
+// T5 head off EPI_ANY, whose run-time activation switch spills (784 B of scratch per lane: 308 vs ~900 TFLOP/s)
+enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_QGELU = 2, EPI_DGELU = 3, EPI_DQGELU = 4, EPI_ANY = 5, EPI_DMUL = 6, EPI_RELU = 7 };
 
 struct MfmaArgs {
     const bf16_t* A; int64_t lda;
@@ -141,8 +143,8 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] += y[t];
     }
-    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
-        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
+    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_RELU || EPI == EPI_ANY) {
+        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : (EPI == EPI_RELU ? M3AE_ACT_RELU : a.act));
         if (a.preact && a.preact_grad) {
             float dd[4];
             act_fwd_grad_fast_n<4>(x, dd, act);
@@ -152,7 +154,7 @@ DEVINL void epilogue4(const MfmaArgs& a, int64_t m, int64_t n, f32x4 v) {
             act_fwd_fast_n<4>(x, act);
         }
     }
-    if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
+    if ((EPI == EPI_PLAIN || EPI == EPI_ANY || EPI == EPI_RELU || EPI == EPI_DMUL) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);  // N % 4 == 0 on this path: ld = N
     }
     if (a.residual) {
@@ -213,8 +215,8 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += bias8[t];
     }
-    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_ANY) {
-        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : a.act);
+    if (EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_RELU || EPI == EPI_ANY) {
+        const int act = EPI == EPI_GELU ? M3AE_ACT_GELU : (EPI == EPI_QGELU ? M3AE_ACT_QUICKGELU : (EPI == EPI_RELU ? M3AE_ACT_RELU : a.act));
         if (a.preact && a.preact_grad) {
             float dd[8];
             act_fwd_grad_fast_n<8>(x, dd, act);
@@ -224,7 +226,7 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
             act_fwd_fast_n<8>(x, act);
         }
     }
-    if ((EPI == EPI_PLAIN || EPI == EPI_ANY) && a.has_drop) {  // dropout follows a plain dense layer on this path
+    if ((EPI == EPI_PLAIN || EPI == EPI_ANY || EPI == EPI_RELU || EPI == EPI_DMUL) && a.has_drop) {  // dropout follows a plain dense layer on this path
         drop_apply4(a.drop, (uint64_t)(m * a.N + n), x);
         drop_apply4(a.drop, (uint64_t)(m * a.N + n + 4), x + 4);
     }
@@ -1108,10 +1110,11 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.drop = make_drop(d.dropout_p, d.dropout_seed);
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
+    if (!has_dact && d.act == M3AE_ACT_RELU) return launch_nt_v<EPI_RELU>(a, s);                       // dropout allowed
+    if (!has_act && has_dact && d.dact == M3AE_ACT_MULAUX) return launch_nt_v<EPI_DMUL>(a, s);          // dropout allowed
     if (a.has_drop) return launch_nt_v<EPI_ANY>(a, s);
     if (!has_dact && d.act == M3AE_ACT_GELU) return launch_nt_v<EPI_GELU>(a, s);
     if (!has_dact && d.act == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_QGELU>(a, s);
-    if (!has_act && has_dact && d.dact == M3AE_ACT_MULAUX) return launch_nt_v<EPI_DMUL>(a, s);
     if (!has_act && d.dact == M3AE_ACT_GELU) return launch_nt_v<EPI_DGELU>(a, s);
     if (!has_act && d.dact == M3AE_ACT_QUICKGELU) return launch_nt_v<EPI_DQGELU>(a, s);
     return launch_nt_v<EPI_ANY>(a, s);
