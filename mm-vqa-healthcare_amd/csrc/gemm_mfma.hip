@@ -1070,12 +1070,18 @@ static int launch_nt_dual(const MfmaArgs& a0, hipStream_t s) {
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
-        // the 256 x 256 ping-pong kernel runs one workgroup per CU: it needs at least two full rounds of tiles to beat the
-        // 128 x 128 kernel (text stream at per-GPU batch 256, M = 8192: 96 .. 384 tiles -> 18 vs 25 us, 47 vs 66 us)
-        const bool big = cdiv(a.M, 256) * cdiv(a.N, 256) >= 512;
-        // ping-pong kernel (variant 7): 1232 / 1340 TF/s at 4096^3 / 8192^3, +3..10 % over the 2-stage kernel on the
-        // path's own shapes (profiles/r01_gemm_shapes.log)
-        if (big && g_nt_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
+        // 256 x 256 ping-pong kernel (one workgroup per CU, 256 slots) or 128 x 128 kernel (two per CU, 512 slots)?  What
+        // decides is how full the last round of tiles is: efficiency = tiles / (rounds * slots).  The ping-pong kernel is
+        // ~12 % faster per FLOP on full rounds, so it is taken when eff256 >= 0.88 eff128.  Fits every measured pair
+        // (MI355X, K = 768 / 3072): 8192 x 3072 (0.75 vs 1.00: 66 vs 47 us -> 128), 8192 x 768 (0.38 vs 0.75 -> 128),
+        // 36928 x 768 (0.85 vs 0.85: 54 vs 57 us, 164 vs 181 us -> 256), 3072 x 3072 (0.56 vs 0.56: 25.7 vs 26.0 us),
+        // 2048 x 3072 (0.38 vs 0.75: 23.5 vs 17.1 us -> 128); profiles/r01_gemm_shapes.log, r01_nt_tile_rule.log.
+        const int64_t t256 = cdiv(a.M, 256) * cdiv(a.N, 256), t128 = cdiv(a.M, 128) * cdiv(a.N, 128);
+        const double eff256 = (double)t256 / (double)(cdiv(t256, 256) * 256);
+        const double eff128 = (double)t128 / (double)(cdiv(t128, 512) * 512);
+        const bool big = a.M > 128 && a.N > 128 && eff256 >= 0.88 * eff128;
+        const bool persist_ok = t256 >= 512;   // the persistent form pays from two full rounds on (+1..3 %)
+        if (big && persist_ok && g_nt_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }

@@ -11,7 +11,7 @@ from m3ae_amd import _lib, ops  # noqa: E402
 B = int(os.environ.get("B", 64))
 VARS = tuple(int(v) for v in os.environ.get('VARS', '0,4,7').split(','))
 M = B * 577
-NT_SHAPES = [(M, 3072, 768)] if os.environ.get('TN_ONLY') else [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768), (B * 32, 768, 3072), (B * 32, 2304, 768),
+NT_SHAPES = [(M, 3072, 768)] if os.environ.get('TN_ONLY') else [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768), (B * 32, 3072, 768), (B * 32, 768, 3072), (B * 32, 2304, 768), (B * 32, 1536, 768),
              (4096, 4096, 4096), (8192, 8192, 8192)]
 TN_SHAPES = [(M, 768, 768), (M, 2304, 768), (M, 3072, 768), (M, 768, 3072), (B * 32, 768, 768)]
 
@@ -43,7 +43,7 @@ def main():
                 ms = time_it(lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k))
                 res.append((v, ms))
         best = {v: min(ms for vv, ms in res if vv == v) for v in VARS}
-        print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"v{v}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in VARS), flush=True)
+        print(f"NT {m:6d}x{n:5d}x{k:5d}: " + "  ".join(f"{('auto' if v < 0 else 'v' + str(v))}: {best[v]*1e3:8.1f} us {2.0*m*n*k/best[v]/1e9:7.1f} TF/s" for v in VARS), flush=True)
     # epilogue-heavy forms on the dominant shapes
     m = M
     for vv in tuple(int(v) for v in os.environ.get('EVARS', '0,4,7').split(',')):
