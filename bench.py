@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
+    ap.add_argument("--rehearse-ddp", action="store_true",
+                    help="single GPU only: run the N > 1 code path (one-rank RCCL group, bucketed async all-reduces from the "
+                         "backward hooks, one-tile-per-workgroup NT launches) -- a rehearsal of the scaling run, not a metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,6 +95,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.rehearse_ddp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from m3ae_amd import ops, synth
     from m3ae_amd.config import finetune_vqa_rad_config
@@ -125,7 +133,11 @@ def main():
     # is part of the step in every mode
     model.train(not args.no_dropout)
     store = model.store
-    reducer = FlatGradReducer(store).attach()
+    reducer = FlatGradReducer(store)
+    if args.rehearse_ddp and world == 1:
+        reducer.world = 2          # take the hook / bucket path; the sum over one rank is the identity
+    reducer.attach()
+    ddp_scale = 1.0 if (args.rehearse_ddp and world == 1) else None
 
     log("model resident; generating synthetic batch")
     B = args.batch
@@ -147,7 +159,7 @@ def main():
         loss = train_loss()
         loss.backward()
         reducer.finish()
-        store.adamw_step(max_steps=max_steps, grad_scale=reducer.grad_scale)
+        store.adamw_step(max_steps=max_steps, grad_scale=ddp_scale if ddp_scale is not None else reducer.grad_scale)
         return loss
 
     for i in range(args.warmup):
@@ -305,7 +317,9 @@ def main():
                              "trainable (main_t5_m3ae.py)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "dropout": ("p=0.1 at every dropout site of the model (train mode, as the reference)" if model.training
-                                   else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)"},
+                                   else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)",
+                       **({"rehearsal": "N > 1 code path on one GPU (one-rank RCCL group); not the metric's configuration"}
+                          if args.rehearse_ddp else {})},
             "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1) if args.head == "cls" else None,
             "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
             if args.head == "cls" else None,
@@ -320,6 +334,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 runs the roofline / cpu_baseline legs alone; the others wait here, not in teardown
+        dist.destroy_process_group()
+    elif args.rehearse_ddp:
         dist.destroy_process_group()
 
 
