@@ -118,6 +118,51 @@ int m3ae_attn_fwd(const m3ae_attn_desc* d, void* stream);
 int m3ae_attn_bwd(const m3ae_attn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Fused cross-attention sub-block of BertCrossLayer (north_star's kernel), bf16: BertAttention as `crossattention`
+ * (bert_model.py:480-488) = BertSelfAttention.forward cross branch (:253-350, :275-278) + BertSelfOutput (:353-364):
+ *     out = LayerNorm(x + dropout(dense(softmax(QK^T / sqrt(dh) + mask) V)))     Q from x, K / V from y.
+ * The projection of the LONG side (the 577 image tokens) is absorbed into the short side (32 text tokens); see
+ * csrc/xattn.hip.  dir 0: text queries over image keys (Lq = 32); dir 1: image queries over text keys (Lk = 32).
+ * Results equal the unfused composition (m3ae_gemm + m3ae_attn_fwd + m3ae_gemm + m3ae_layernorm_fwd) up to bf16
+ * rounding of the intermediates; the dropout masks are THE SAME masks (same seeds, same index convention), so the
+ * two can be compared under dropout.  All buffers are caller-owned; the intermediates are what the backward reads.
+ *   weights (bf16): wq [D, D], wq_t = wq^T, wkv [2D, D] (key rows, then value rows), wkv_t = wkv^T [D, 2D], wo [D, D],
+ *                   wo_t = wo^T; biases and LayerNorm parameters fp32.
+ *   key_mask: additive fp32 [B, Lk] or NULL.
+ *   proj:  dir 0: q [B*Lq, D];          dir 1: k | v [B*Lk, 2D]
+ *   prime: dir 0: Q' [B, Lq*H, D];      dir 1: K' then V', each [B, H*Lk, D]
+ *   colbias (dir 1): fp32 [B, H*Lk].    probs / probs_drop: dir 0 [B, Lq*H, 640]; dir 1 [B, Lq, H*Lk]
+ *   (probs_drop, rowsum [B, Lq*H] fp32 (dir 0): only with dropout_p > 0).   zctx (dir 0): [B, Lq*H, D]; ctx (dir 0): [B*Lq, D]
+ *   s: pre-LayerNorm sum [B*Lq, D]; out [B*Lq, D]; mean / rstd fp32 [B*Lq].
+ */
+typedef struct {
+    int32_t dir;
+    int64_t B, Lq, Lk, D, H;
+    const void* x;
+    const void* y;
+    const float* key_mask;
+    const void *wq, *wq_t, *wkv, *wkv_t, *wo, *wo_t;
+    const float *bq, *bkv, *bo, *ln_g, *ln_b;
+    float ln_eps;
+    float dropout_p;
+    uint64_t seed_attn, seed_hidden;
+    void* proj;
+    void* prime;
+    float* colbias;
+    void* probs;
+    void* probs_drop;
+    float* rowsum;
+    void* zctx;
+    void* ctx;
+    void* s;
+    void* out;
+    float *mean, *rstd;
+} m3ae_xattn_desc;
+int m3ae_xattn_supported(const m3ae_xattn_desc* d);   /* 1 if the fused kernels cover these shapes */
+int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d);
+int m3ae_xattn_fwd(const m3ae_xattn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * LayerNorm (biased variance, eps inside the sqrt, fp32 statistics), optional fused activation on the output.
  * Replaces nn.LayerNorm at bert_model.py:357,363,435,441 (eps 1e-12 / 1e-5), clip_model.py:27-33 (fp32 upcast),
  * m3ae_module.py:122 (+ nn.GELU :123 via `act`).  mean / rstd: fp32 [M] saved for backward.

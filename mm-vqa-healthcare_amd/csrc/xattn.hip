@@ -1,0 +1,753 @@
+// Fused cross-attention sub-block of BertCrossLayer for gfx950 (north_star's kernel; reference:
+// m3ae/modules/language_encoders/bert_model.py:253-350 (cross branch :275-278), :353-364, :480-488).
+//
+// Both directions of the co-attention have ONE long side (image, I = 577 tokens) and one short side (text, T = 32
+// tokens), and H * T = 384 < D = 768.  The projection of the long side is therefore absorbed into the short side:
+//
+//   text queries  (dir 0, Lq = T, Lk = I):   S_h = Q_h K_h^T = (Q_h W_k,h) y^T + [row constant: drops out of softmax]
+//        Q' = (q_h / sqrt(dh)) W_k,h   [B, T*H, D]           (rows r = t*H + h)
+//        P  = softmax_rows(Q' y^T + mask)                    [B, T*H, I]     one GEMM per sample, K = D
+//        Z  = drop(P) y                                      [B, T*H, D]     one GEMM per sample, K = I
+//        ctx_h = Z_h W_v,h^T + rowsum(drop(P)) b_v,h         [B*T, D]
+//   image queries (dir 1, Lq = I, Lk = T):   S_h = x (K_h W_q,h)^T + b_q,h K_h^T
+//        K' = (k_h / sqrt(dh)) W_q,h   [B, H*T, D],  V' = v_h W_o[:, h]^T   [B, H*T, D]   (rows n = h*T + j)
+//        P  = softmax_32-column-groups(x K'^T + c),  c[n] = b_q,h . k_h[j] / sqrt(dh) + mask[j]      [B, I, H*T]
+//        out = drop(P) V' + b_o                              [B*I, D]        (the output dense is absorbed as well)
+//
+// so the 577-token K/V (dir 0) and Q/output (dir 1) projections -- 2 x 0.68 GFLOP per sample and direction -- become
+// two [384 x 577 x 768] products (2 x 0.34 GFLOP), and the softmax runs in the epilogue of the score GEMM.  b_k drops
+// out of the softmax exactly (it adds the same number to every key of a row).
+//
+// All big products run on ONE kernel template (xg_kernel): per-sample batched bf16 MFMA GEMM in the ping-pong
+// structure of gemm_nt_pp_kernel (8 waves in two barrier-staggered groups, 32-deep chunks DMA-staged into an LDS ring,
+// counted vmcnt), with the tile shape, the operand forms (K-contiguous rows or reduction-strided [K][cols] read with
+// ds_read_b64_tr_b16) and the epilogue as template parameters.
+#include "mfma_tiles.h"
+
+namespace {
+
+enum { FORM_K = 0, FORM_T = 1 };
+enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3 };
+
+struct XgArgs {
+    const bf16_t* A; int64_t lda, a_sb;    // FORM_K: [M][K] (lda = row stride); FORM_T: [K][M] (lda = stride of a k row)
+    const bf16_t* B; int64_t ldb, b_sb;    // FORM_K: [N][K];                    FORM_T: [K][N]
+    int M, N, K;                           // per batch item; FORM_K operands are readable (zero / finite) up to ceil32(K)
+    int tiles_m, tiles_n;
+    bf16_t* C; int64_t ldc, c_sb;
+    bf16_t* C2;                            // softmax epilogues: the dropped probabilities (same layout), or nullptr
+    int rdiv, rmul;                        // XE_STORE row map: crow = (m / rdiv) * rmul + m % rdiv   (rdiv = 0: identity)
+    float alpha;
+    const float* bias; int64_t bias_sb;    // [N] (+ batch * bias_sb)
+    const float* rowscale; int64_t rs_sm, rs_sb;   // XE_STORE: bias is multiplied by rowscale[m * rs_sm + batch * rs_sb]
+    const bf16_t* residual;                // XE_DENSE: [batch * M + m][ldc]
+    const float* colbias; int64_t cb_sb;   // softmax epilogues: additive [batch][N] (nullptr: none)
+    float* rowsum_out;                     // XE_SOFTMAXROW with dropout: [batch][M] row sums of the dropped probabilities
+    int n_valid;                           // XE_SOFTMAXROW: columns >= n_valid are masked out (P = 0)
+    DropState drop; int has_drop;
+    int H, Lq, drop_ld;                    // dropout index convention of m3ae_attn_desc: ((b*H + h)*Lq + q) * ld + k
+    int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
+};
+
+// one 1-KiB piece (4 rows) of a [32 k-rows][128 cols] panel of a reduction-strided operand; piece = 0..7
+DEVINL void t_stage128(const bf16_t* G, int64_t ld, int r0, int r_end, int col0, int ncols, char* panel, int piece,
+                       int lane) {
+    const int wave = piece;
+    const int row = wave * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ tn_swz(row);
+    const int grow = r0 + row, col = col0 + chunk * 8;
+    const void* src = (grow < r_end && col < ncols) ? (const void*)(G + (int64_t)grow * ld + col)
+                                                    : (const void*)((const char*)g_m3ae_zero_page + (lane & 15) * 16);
+    glds16(src, panel + wave * 1024);
+}
+
+template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int G> DEVINL void wait_vm_chunks(int chunks) {   // chunks in {0, 1, 2}
+    if (chunks >= 2) wait_vm<2 * G>();
+    else if (chunks == 1) wait_vm<G>();
+    else wait_vm<0>();
+}
+
+DEVINL float quad16_max(float v) {   // over the 4 lanes l, l^16, l^32, l^48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+DEVINL float quad16_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+DEVINL void st_bf4(bf16_t* p, const float* x) { *(u32x2*)p = (u32x2){pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}; }
+DEVINL void ld_bf4(const bf16_t* p, float* x) {
+    const u32x2 v = *(const u32x2*)p;
+    x[0] = __uint_as_float(v[0] << 16); x[1] = __uint_as_float(v[0] & 0xffff0000u);
+    x[2] = __uint_as_float(v[1] << 16); x[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+#ifdef M3AE_XG_TRACE   // diagnostic build only (tools/xg_trace.py): per-workgroup timeline stamps, never in the product build
+__device__ uint64_t g_xg_trace[8 * 16 * 4096];   // [launch slot][block][4 x 100-MHz ticks, 4 x shader clocks, 8 in-loop clocks]
+#define XG_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) { uint64_t* t_ = g_xg_trace + ((size_t)a.trace_slot * 4096 + blockIdx.x) * 16; \
+                                                             t_[(k)] = __builtin_amdgcn_s_memrealtime(); t_[4 + (k)] = __builtin_readcyclecounter(); } } while (0)
+// in-loop stamps of chunk 8 (shader clocks), wave 0 of the workgroup
+#define XG_LSTAMP(k) do { if (c == 8 && tid == 0 && blockIdx.x < 4096) g_xg_trace[((size_t)a.trace_slot * 4096 + blockIdx.x) * 16 + 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XG_STAMP(k) do { } while (0)
+#define XG_LSTAMP(k) do { } while (0)
+#endif
+
+// ---- epilogue plumbing: the wave's accumulators reach memory through a wave-private LDS slab, 32 rows at a time, so that
+// every global access is 16 B per lane along a row (row-scattered 8-byte accesses straight from the MFMA layout run at
+// ~7 B/clk/CU: measured 2-3x the main loop on these shapes).  A slab pass is [32 rows][WN cols] with 16 B of row padding;
+// "piece" = 8 consecutive columns of one row; lane l handles pieces l, l + 64, ...
+template <int WN, int ES> struct Slab {   // ES = element bytes (2: bf16, 4: fp32)
+    static constexpr int RS = WN * ES + 16, BYTES = 32 * RS, PR = WN / 8, PPL = 32 * PR / 64;
+    static_assert((32 * PR) % 64 == 0, "pieces per lane");
+};
+// lane's 4 values of row 16 ii + (lane & 15), columns 16 j + 4 (lane >> 4) .. + 3
+template <int WN> DEVINL void slab_put_bf16(char* slab, int lane, int ii, int j, const float* v) {
+    *(u32x2*)(slab + (16 * ii + (lane & 15)) * Slab<WN, 2>::RS + (16 * j + 4 * (lane >> 4)) * 2) =
+        (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+}
+template <int WN> DEVINL void slab_put_f32(char* slab, int lane, int ii, int j, f32x4 v) {
+    *(f32x4*)(slab + (16 * ii + (lane & 15)) * Slab<WN, 4>::RS + (16 * j + 4 * (lane >> 4)) * 4) = v;
+}
+// store one bf16 slab pass: rowptr(r) = global address of column n_w of slab row r (nullptr: row out of range)
+template <int WN, class RowPtr> DEVINL void slab_store_bf16(const char* slab, int lane, int ncols_ok, RowPtr rowptr) {
+    using S = Slab<WN, 2>;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < S::PPL; ++t) {
+        const int piece = lane + 64 * t, row = piece / S::PR, c8 = piece - row * S::PR;
+        const u32x4 v = *(const u32x4*)(slab + row * S::RS + c8 * 16);
+        bf16_t* p = rowptr(row);
+        if (p != nullptr && c8 * 8 < ncols_ok) *(u32x4*)(p + c8 * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab may be overwritten by the next pass
+}
+
+// BM x BN output tile of batch item `bi`.  12 waves: 8 COMPUTE waves as WAVES_M x (8 / WAVES_M), each (BM / WAVES_M) x
+// (BN / WAVES_N), in two groups (waves 0-3 / 4-7: one wave of each per SIMD) that run one barrier apart, so one group's
+// MFMA cluster covers the other's fragment reads; and 4 LOADER waves (one per SIMD) that do nothing but request the
+// 32-deep operand chunks (LDS-DMA, 1-KiB pieces) into an NSLOT-slot ring, NSLOT - 1 chunks ahead.
+// Why loaders: the LDS-DMA path of a CU moves ~30 B/clk; when the compute waves issue the pieces themselves, every piece
+// stalls its wave for ~135 clk (measured: 540 clk per wave and chunk at 4 pieces, in-kernel stamps) in the read section
+// that the partner group's MFMAs are supposed to hide -- the section grows to twice the MFMA cluster and the chunk period
+// with it (2200 clk against 2 x 384 of MFMA).  A loader's stalls cost nothing.
+//   compute phase c:  [fragment reads of chunk c; lgkmcnt(0)]  barrier  [MI x NJ MFMAs]  barrier
+//   loader  phase c:  [request chunk c + NSLOT - 1 into the slot of chunk c - 1; counted vmcnt: chunk c + 1 landed]  barrier  barrier
+// Ring safety: the loaders run in step with the early group.  RAW: a loader's wait for chunk c + 1 precedes its first
+// barrier of phase c; the early group reads chunk c + 1 after its second barrier of phase c, the late group later still.
+// WAR: chunk c + NSLOT - 1 overwrites chunk c - 1, whose reads every compute wave retired (lgkmcnt(0)) BEFORE the first
+// barrier of its phase c - 1; for the late group that barrier is the loaders' second barrier of phase c - 1.
+// Lane layout of the accumulators (D'[n][m] orientation, as gemm_nt_pp_kernel): acc[i][j][r] =
+// C[m = .. + 16 i + (lane & 15)][n = .. + 16 j + 4 (lane >> 4) + r].
+template <int BM, int BN, int WAVES_M, int NSLOT, int AFORM, int BFORM, int EPI>
+__global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
+    constexpr int WAVES_N = 8 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
+    constexpr int NLOAD = 4, GA = BM / 16 / NLOAD, GB = BN / 16 / NLOAD, G = GA + GB, DEPTH = NSLOT - 1;
+    constexpr int A_BYTES = BM * 64, SLOT = (BM + BN) * 64;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && WM % 16 == 0 && WN % 16 == 0 && DEPTH >= 2 && DEPTH <= 3, "tile shape");
+    static_assert((AFORM == FORM_K || BM % 128 == 0) && (BFORM == FORM_K || BN % 128 == 0), "T-form operands come in 128-column panels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const unsigned per_b = (unsigned)(a.tiles_m * a.tiles_n);
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);   // an XCD walks a contiguous range: a sample's tiles share its L2
+    const unsigned bi = wg / per_b, tt = wg - bi * per_b;
+    const int m0 = (int)(tt / a.tiles_n) * BM, n0 = (int)(tt % a.tiles_n) * BN;
+    const int nc = (a.K + 31) >> 5;
+    XG_STAMP(0);
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------------ loader waves
+        const int lw = wave - 8;
+        const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
+        const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
+        auto stage = [&](int c, char* slot) {
+            if constexpr (BFORM == FORM_K) nt_stage<32, GB, NLOAD>(B, a.ldb, n0, a.N, (int64_t)c * 32, slot + A_BYTES, lw, lane);
+            else {
+#pragma unroll
+                for (int p = 0; p < BN / 128; ++p)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        t_stage128(B, a.ldb, c * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + 4 * h, lane);
+            }
+            if constexpr (AFORM == FORM_K) nt_stage<32, GA, NLOAD>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
+            else {
+#pragma unroll
+                for (int p = 0; p < BM / 128; ++p)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        t_stage128(A, a.lda, c * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + 4 * h, lane);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < DEPTH; ++c)
+            if (c < nc) stage(c, smem + c * SLOT);
+        wait_vm_chunks<G>((nc < DEPTH ? nc : DEPTH) - 1);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();   // chunk 0 is in LDS
+        PP_FENCE();
+        int nxt = DEPTH;
+        for (int c = 0; c < nc; ++c) {
+            if (c + DEPTH < nc) stage(c + DEPTH, smem + nxt * SLOT);
+            const int rem = nc - 1 - c;
+            wait_vm_chunks<G>(rem >= 1 ? (rem - 1 < DEPTH - 1 ? rem - 1 : DEPTH - 1) : 0);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            nxt = nxt + 1 == NSLOT ? 0 : nxt + 1;
+        }
+        __builtin_amdgcn_s_barrier();   // the early group's re-alignment barrier
+        return;                         // ended waves are not counted by the epilogue's barriers
+    }
+
+    // --------------------------------------------------------------------------------------------------- compute waves
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const bool late = wave >= 4;
+    // per-lane fragment offsets inside a slot (loop-invariant)
+    int aoff[MI][2], boff[NJ][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = wr * WM + i * 16;
+        if constexpr (AFORM == FORM_K) { aoff[i][0] = nt_frag_off<32>(r + (lane & 15), lane >> 4); aoff[i][1] = 0; }
+        else { tn_frag_offs<128>(r & 127, lane, aoff[i][0], aoff[i][1]); aoff[i][0] += (r >> 7) * 8192; aoff[i][1] += (r >> 7) * 8192; }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = wc * WN + j * 16;
+        if constexpr (BFORM == FORM_K) { boff[j][0] = A_BYTES + nt_frag_off<32>(r + (lane & 15), lane >> 4); boff[j][1] = 0; }
+        else { tn_frag_offs<128>(r & 127, lane, boff[j][0], boff[j][1]); boff[j][0] += A_BYTES + (r >> 7) * 8192; boff[j][1] += A_BYTES + (r >> 7) * 8192; }
+    }
+    auto frag_a = [&](const char* slot, int i) -> s16x8 {
+        if constexpr (AFORM == FORM_K) return nt_frag_at(slot, aoff[i][0]);
+        else return tn_frag_at(slot, aoff[i][0], aoff[i][1]);
+    };
+    auto frag_b = [&](const char* slot, int j) -> s16x8 {
+        if constexpr (BFORM == FORM_K) return nt_frag_at(slot, boff[j][0]);
+        else return tn_frag_at(slot, boff[j][0], boff[j][1]);
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    PP_FENCE();
+    __builtin_amdgcn_s_barrier();   // chunk 0 is in LDS
+    PP_FENCE();
+    if (late) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+    XG_STAMP(1);
+
+    int cur = 0;
+    for (int c = 0; c < nc; ++c) {
+        const char* At = smem + cur * SLOT;
+        s16x8 bfr[NJ], af[MI];
+        XG_LSTAMP(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = frag_b(At, j);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = frag_a(At, i);
+        XG_LSTAMP(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers, the slot's reads retired, before the barrier
+        XG_LSTAMP(2);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        XG_LSTAMP(3);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        XG_LSTAMP(4);
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();
+        PP_FENCE();
+        XG_LSTAMP(5);
+        cur = cur + 1 == NSLOT ? 0 : cur + 1;
+    }
+    if (!late) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // re-align: every wave has executed the same number of barriers
+    // every fragment read is retired and no DMA is outstanding: the ring is free
+    XG_STAMP(2);
+
+    const int mw0 = m0 + wr * WM;                         // first row of the wave's sub-tile
+    const int nw0 = n0 + wc * WN;                         // first column
+    const int mw = mw0 + (lane & 15);                     // + 16 i: this lane's row in the accumulator layout
+    const int nw = nw0 + 4 * (lane >> 4);                 // + 16 j
+    const int ncols_ok = a.N - nw0;                       // columns of the sub-tile inside the matrix (multiple of 8)
+    constexpr int SLAB_STRIDE = Slab<WN, EPI == XE_DENSE ? 4 : 2>::BYTES;   // per-wave slab region
+    char* slab = smem + wave * SLAB_STRIDE;
+    static_assert(8 * SLAB_STRIDE + 4 * WAVES_N * BM <= NSLOT * SLOT, "slabs + reduction scratch fit the ring");
+    float* red = (float*)(smem + 8 * SLAB_STRIDE);        // [WAVES_N][BM] cross-wave reduction scratch (XE_SOFTMAXROW)
+
+    if constexpr (EPI == XE_STORE) {
+        bf16_t* C = a.C + (int64_t)bi * a.c_sb;
+        const float* bias = a.bias ? a.bias + (int64_t)bi * a.bias_sb : nullptr;
+#pragma unroll
+        for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * ps + ii, m = mw + 16 * i;
+                const float rs = (a.rowscale && m < a.M) ? a.rowscale[(int64_t)m * a.rs_sm + (int64_t)bi * a.rs_sb] : 1.0f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = nw + 16 * j;
+                    float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+                    if (bias && n < a.N) {
+                        const f32x4 b4 = *(const f32x4*)(bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(b4[r], rs, v[r]);
+                    }
+                    slab_put_bf16<WN>(slab, lane, ii, j, v);
+                }
+            }
+            slab_store_bf16<WN>(slab, lane, ncols_ok, [&](int row) -> bf16_t* {
+                const int m = mw0 + 32 * ps + row;
+                if (m >= a.M) return nullptr;
+                const int64_t crow = a.rdiv ? (int64_t)(m / a.rdiv) * a.rmul + (m % a.rdiv) : (int64_t)m;
+                return C + crow * a.ldc + nw0;
+            });
+        }
+    } else if constexpr (EPI == XE_DENSE) {
+        // BertSelfOutput (bert_model.py:360-364) up to the LayerNorm: dropout(dense) + residual; dropout index = the GEMM
+        // epilogue's (row of the [B * M, N] matrix) * N + n.  bias and dropout in the accumulator layout, the residual add
+        // on the row-contiguous side of the (fp32) slab; the residual pieces are requested before the slab passes
+        using S = Slab<WN, 4>;
+#pragma unroll
+        for (int ps = 0; ps < MI / 2; ++ps) {
+            u32x4 res[S::PPL];   // this pass's residual pieces, requested before the slab round trip
+#pragma unroll
+            for (int t = 0; t < S::PPL; ++t) {
+                const int piece = lane + 64 * t, row = piece / S::PR, c8 = piece - row * S::PR;
+                const int m = mw0 + 32 * ps + row;
+                res[t] = (u32x4){0u, 0u, 0u, 0u};
+                if (a.residual && m < a.M && c8 * 8 < ncols_ok)
+                    res[t] = *(const u32x4*)(a.residual + ((int64_t)bi * a.M + m) * a.ldc + nw0 + c8 * 8);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * ps + ii;
+                const int64_t gm = (int64_t)bi * a.M + mw + 16 * i;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = nw + 16 * j;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (a.bias && n < a.N) {
+                        const f32x4 b4 = *(const f32x4*)(a.bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += b4[r];
+                    }
+                    if (a.has_drop) drop_apply4(a.drop, (uint64_t)(gm * a.N + n), v);
+                    slab_put_f32<WN>(slab, lane, ii, j, (f32x4){v[0], v[1], v[2], v[3]});
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < S::PPL; ++t) {
+                const int piece = lane + 64 * t, row = piece / S::PR, c8 = piece - row * S::PR;
+                const f32x4 v0 = *(const f32x4*)(slab + row * S::RS + c8 * 32);
+                const f32x4 v1 = *(const f32x4*)(slab + row * S::RS + c8 * 32 + 16);
+                const u32x4 rr = res[t];
+                float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[2 * q] += __uint_as_float(rr[q] << 16);
+                    x[2 * q + 1] += __uint_as_float(rr[q] & 0xffff0000u);
+                }
+                const int m = mw0 + 32 * ps + row;
+                if (m < a.M && c8 * 8 < ncols_ok)
+                    *(u32x4*)(a.C + ((int64_t)bi * a.M + m) * a.ldc + nw0 + c8 * 8) =
+                        (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (EPI == XE_SOFTMAX32) {
+        // image queries: column n = h * 32 + j; one softmax per (row, head) = one pair of 16-column blocks of this wave
+        static_assert(NJ % 2 == 0, "heads are pairs of 16-column blocks");
+        bf16_t* P = a.C + (int64_t)bi * a.c_sb;
+        bf16_t* Pd = a.C2 ? a.C2 + (int64_t)bi * a.c_sb : nullptr;
+        const float* cb = a.colbias ? a.colbias + (int64_t)bi * a.cb_sb : nullptr;
+#pragma unroll
+        for (int g = 0; g < NJ / 2; ++g) {
+            const int n = nw + 32 * g;        // this lane's columns: n .. n + 3 and n + 16 .. n + 19
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            if (cb && n < a.N) { c0 = *(const f32x4*)(cb + n); c1 = *(const f32x4*)(cb + n + 16); }   // N % 32 == 0
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = (acc[i][2 * g][r] * a.alpha + c0[r]) * LOG2E;
+                    v[4 + r] = (acc[i][2 * g + 1][r] * a.alpha + c1[r]) * LOG2E;
+                }
+                float mx = v[0];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, v[r]);
+                mx = quad16_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { v[r] = __builtin_amdgcn_exp2f(v[r] - mx); sum += v[r]; }
+                sum = quad16_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[i][2 * g][r] = v[r] * inv; acc[i][2 * g + 1][r] = v[4 + r] * inv; }
+            }
+        }
+#pragma unroll
+        for (int out = 0; out < 2; ++out) {
+            if (out == 1 && Pd == nullptr) break;
+            bf16_t* dst = out == 0 ? P : Pd;
+#pragma unroll
+            for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * ps + ii, m = mw + 16 * i;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (out == 1) {   // attention-probability dropout (bert_model.py:334): index ((b H + h) Lq + q) ld + k
+                            const int n = nw + 16 * j;
+                            const uint64_t base = ((uint64_t)((int64_t)bi * a.H + (n >> 5)) * a.Lq + m) * a.drop_ld;
+                            drop_apply4(a.drop, base + (n & 31), v);
+                        }
+                        slab_put_bf16<WN>(slab, lane, ii, j, v);
+                    }
+                }
+                slab_store_bf16<WN>(slab, lane, ncols_ok, [&](int row) -> bf16_t* {
+                    const int m = mw0 + 32 * ps + row;
+                    return m < a.M ? dst + (int64_t)m * a.ldc + nw0 : nullptr;
+                });
+            }
+        }
+    } else if constexpr (EPI == XE_SOFTMAXROW) {
+        // text queries: the tile holds whole rows (n0 == 0, BN >= n_valid); a row is spread over the WAVES_N waves of a
+        // wave row: max and sum go through LDS
+        bf16_t* P = a.C + (int64_t)bi * a.c_sb;
+        bf16_t* Pd = a.C2 ? a.C2 + (int64_t)bi * a.c_sb : nullptr;
+        const float* cb = a.colbias ? a.colbias + (int64_t)bi * a.cb_sb : nullptr;
+        const int rl = wr * WM + (lane & 15);          // row inside the tile, + 16 i
+        float mx[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) mx[i] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nw + 16 * j;
+            float c4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cb) {   // additive key mask [batch][n_valid] (n_valid is odd in general: scalar loads)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.n_valid) c4[r] = cb[n + r];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (n + r < a.n_valid) ? (acc[i][j][r] * a.alpha + c4[r]) * LOG2E : -INFINITY;
+                    acc[i][j][r] = v;
+                    mx[i] = fmaxf(mx[i], v);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            mx[i] = quad16_max(mx[i]);
+            if (lane < 16) red[wc * BM + rl + 16 * i] = mx[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float m_ = red[rl + 16 * i];
+#pragma unroll
+            for (int w = 1; w < WAVES_N; ++w) m_ = fmaxf(m_, red[w * BM + rl + 16 * i]);
+            mx[i] = m_;
+        }
+        __syncthreads();
+        float sm[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(acc[i][j][r] - mx[i]);
+                    acc[i][j][r] = e;
+                    s_ += e;
+                }
+            s_ = quad16_sum(s_);
+            if (lane < 16) red[wc * BM + rl + 16 * i] = s_;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float s_ = red[rl + 16 * i];
+#pragma unroll
+            for (int w = 1; w < WAVES_N; ++w) s_ += red[w * BM + rl + 16 * i];
+            sm[i] = __builtin_amdgcn_rcpf(s_);
+        }
+        float dsum[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) dsum[i] = 0.f;
+#pragma unroll
+        for (int out = 0; out < 2; ++out) {
+            if (out == 1 && Pd == nullptr) break;
+            bf16_t* dst = out == 0 ? P : Pd;
+#pragma unroll
+            for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * ps + ii, m = mw + 16 * i;   // row r = t * H + h of the sample
+                    const uint64_t base = ((uint64_t)((int64_t)bi * a.H + (m % a.H)) * a.Lq + (m / a.H)) * a.drop_ld;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float v[4];
+                        if (out == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v[r] = acc[i][j][r] * sm[i]; acc[i][j][r] = v[r]; }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+                            drop_apply4(a.drop, base + (nw + 16 * j), v);
+                            dsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                        }
+                        slab_put_bf16<WN>(slab, lane, ii, j, v);
+                    }
+                }
+                slab_store_bf16<WN>(slab, lane, WN, [&](int row) -> bf16_t* {   // every column up to BN: the zero padding is read as K
+                    const int m = mw0 + 32 * ps + row;
+                    return m < a.M ? dst + (int64_t)m * a.ldc + nw0 : nullptr;
+                });
+            }
+        }
+        if (Pd && a.rowsum_out) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float s_ = quad16_sum(dsum[i]);
+                if (lane < 16) red[wc * BM + rl + 16 * i] = s_;
+            }
+            __syncthreads();
+            if (wc == 0 && lane < 16) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float s_ = red[rl + 16 * i];
+#pragma unroll
+                    for (int w = 1; w < WAVES_N; ++w) s_ += red[w * BM + rl + 16 * i];
+                    const int m = mw + 16 * i;
+                    if (m < a.M) a.rowsum_out[(int64_t)bi * a.M + m] = s_;
+                }
+            }
+        }
+    }
+#ifdef M3AE_XG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XG_STAMP(3);
+#endif
+}
+
+#ifdef M3AE_XG_TRACE
+int g_trace_next = 0;
+#endif
+template <int BM, int BN, int WAVES_M, int NSLOT, int AFORM, int BFORM, int EPI>
+int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
+    constexpr int lds = NSLOT * (BM + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&xg_kernel<BM, BN, WAVES_M, NSLOT, AFORM, BFORM, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+#ifdef M3AE_XG_TRACE
+    a.trace_slot = g_trace_next++ & 7;
+#endif
+    const unsigned grid = (unsigned)(nbatch * a.tiles_m * a.tiles_n);
+    hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, AFORM, BFORM, EPI>), dim3(grid), dim3(768), lds, s, a);
+    return hip_launch_status();
+}
+
+// c[b][h * T + j] = scale * sum_d bq[h dh + d] * k[b T + j][h dh + d] + mask[b][j]      (dir 1: the query bias against the keys)
+__global__ __launch_bounds__(256) void xattn_colbias_kernel(const bf16_t* k, int64_t ldk, const float* bq, const float* mask,
+                                                           float* cb, int B, int T, int H, int dh, float scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * T * H) return;
+    const int h = idx % H, j = (idx / H) % T, b = idx / (H * T);
+    const bf16_t* kr = k + (int64_t)(b * T + j) * ldk + h * dh;
+    const float* q = bq + h * dh;
+    float s = 0.f;
+    for (int d = 0; d < dh; d += 8) {
+        const u32x4 v = *(const u32x4*)(kr + d);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s = fmaf(__uint_as_float(v[t] << 16), q[d + 2 * t], s);
+            s = fmaf(__uint_as_float(v[t] & 0xffff0000u), q[d + 2 * t + 1], s);
+        }
+    }
+    cb[(int64_t)b * H * T + h * T + j] = s * scale + (mask ? mask[b * T + j] : 0.f);
+}
+
+}  // namespace
+
+#ifdef M3AE_XG_TRACE
+extern "C" int m3ae_xg_trace_dump(uint64_t* host_out) {   // diagnostic build only: [8 launch slots][4096 blocks][8]; restarts the slots
+    g_trace_next = 0;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xg_trace), sizeof(uint64_t) * 8 * 16 * 4096);
+}
+#endif
+
+extern "C" int m3ae_xattn_supported(const m3ae_xattn_desc* d) {
+    if (!d) return 0;
+    const int64_t T = d->dir == 0 ? d->Lq : d->Lk, I = d->dir == 0 ? d->Lk : d->Lq;
+    if (d->H <= 0 || d->D % d->H != 0) return 0;
+    const int64_t dh = d->D / d->H;
+    return (T == 32 && I >= 1 && I <= 640 && dh % 32 == 0 && d->D % 128 == 0) ? 1 : 0;
+}
+
+extern "C" int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d) {   // row stride (elements) of `probs` / `probs_drop`
+    return d->dir == 0 ? 640 : d->H * d->Lk;
+}
+
+#define XCHK(e) do { const int rc_ = (e); if (rc_ != 0) return rc_; } while (0)
+
+extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
+    if (!dp || !m3ae_xattn_supported(dp)) return M3AE_ERR_UNSUPPORTED;
+    const m3ae_xattn_desc& d = *dp;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)d.B, H = (int)d.H, D = (int)d.D, dh = D / H;
+    const int Lq = (int)d.Lq, Lk = (int)d.Lk;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const bool drop = d.dropout_p > 0.f;
+    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.s || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
+
+    m3ae_gemm_desc g{};
+    g.batch1 = g.batch2 = 1;
+    g.dtype_a = g.dtype_b = g.dtype_c = M3AE_BF16;
+    g.alpha = 1.0f;
+    g.a_sk = g.b_sk = g.c_sn = 1;
+
+    if (d.dir == 0) {
+        const int T = Lq, I = Lk, R = T * H;
+        if (!d.zctx || !d.ctx || (drop && !d.rowsum)) return M3AE_ERR_ARG;
+        // q = x Wq^T + bq                                                         (bert_model.py:263)
+        g.M = (int64_t)B * T; g.N = D; g.K = D;
+        g.A = d.x; g.a_sm = D; g.B = d.wq; g.b_sn = D; g.C = d.proj; g.c_sm = D; g.bias = d.bq;
+        XCHK(m3ae_gemm(&g, stream));
+        {   // Q'[b, t*H + h, :] = scale * q_h Wk_h: one batch item per head, M = B*T rows
+            XgArgs a{};
+            a.A = (const bf16_t*)d.proj; a.lda = D; a.a_sb = dh;
+            a.B = (const bf16_t*)d.wkv_t; a.ldb = 2 * D; a.b_sb = dh;      // Wk^T [c][h dh + d]
+            a.M = B * T; a.N = D; a.K = dh;
+            a.C = (bf16_t*)d.prime; a.ldc = (int64_t)H * D; a.c_sb = D;
+            a.alpha = scale;
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        }
+        {   // P = softmax(Q' y^T + mask) per sample, whole rows per tile
+            XgArgs a{};
+            a.A = (const bf16_t*)d.prime; a.lda = D; a.a_sb = (int64_t)R * D;
+            a.B = (const bf16_t*)d.y; a.ldb = D; a.b_sb = (int64_t)I * D;
+            a.M = R; a.N = I; a.K = D;
+            a.C = (bf16_t*)d.probs; a.ldc = 640; a.c_sb = (int64_t)R * 640;
+            a.C2 = drop ? (bf16_t*)d.probs_drop : nullptr;
+            a.alpha = 1.0f;
+            a.colbias = d.key_mask; a.cb_sb = I;
+            a.rowsum_out = drop ? d.rowsum : nullptr;
+            a.n_valid = I;
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+            a.H = H; a.Lq = T; a.drop_ld = (int)drop_ld(I);
+            XCHK((launch_xg<64, 640, 1, 3, FORM_K, FORM_K, XE_SOFTMAXROW>(a, B, s)));
+        }
+        {   // Z = drop(P) y
+            XgArgs a{};
+            a.A = (const bf16_t*)(drop ? d.probs_drop : d.probs); a.lda = 640; a.a_sb = (int64_t)R * 640;
+            a.B = (const bf16_t*)d.y; a.ldb = D; a.b_sb = (int64_t)I * D;
+            a.M = R; a.N = D; a.K = I;
+            a.C = (bf16_t*)d.zctx; a.ldc = D; a.c_sb = (int64_t)R * D;
+            a.alpha = 1.0f;
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_T, XE_STORE>(a, B, s)));
+        }
+        {   // ctx[b*T + t, h dh + d] = Z[b, t*H + h, :] . Wv[h dh + d, :] + rowsum * bv
+            XgArgs a{};
+            a.A = (const bf16_t*)d.zctx; a.lda = (int64_t)H * D; a.a_sb = D;
+            a.B = (const bf16_t*)d.wkv + (int64_t)D * D; a.ldb = D; a.b_sb = (int64_t)dh * D;
+            a.M = B * T; a.N = dh; a.K = D;
+            a.C = (bf16_t*)d.ctx; a.ldc = D; a.c_sb = dh;
+            a.alpha = 1.0f;
+            a.bias = d.bkv + D; a.bias_sb = dh;
+            if (drop) { a.rowscale = d.rowsum; a.rs_sm = H; a.rs_sb = 1; }
+            XCHK((launch_xg<384, 128, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        }
+        // s = dropout(ctx Wo^T + bo) + x                                          (bert_model.py:361-363)
+        m3ae_gemm_desc o = g;
+        o.M = (int64_t)B * T; o.N = D; o.K = D;
+        o.A = d.ctx; o.a_sm = D; o.B = d.wo; o.b_sn = D; o.C = d.s; o.c_sm = D; o.bias = d.bo; o.residual = d.x;
+        o.dropout_p = d.dropout_p; o.dropout_seed = d.seed_hidden;
+        XCHK(m3ae_gemm(&o, stream));
+    } else {
+        const int I = Lq, T = Lk, R = H * T;
+        if (!d.colbias) return M3AE_ERR_ARG;
+        // k | v = y Wkv^T + bkv                                                   (bert_model.py:276-277)
+        g.M = (int64_t)B * T; g.N = 2 * D; g.K = D;
+        g.A = d.y; g.a_sm = D; g.B = d.wkv; g.b_sn = D; g.C = d.proj; g.c_sm = 2 * D; g.bias = d.bkv;
+        XCHK(m3ae_gemm(&g, stream));
+        bf16_t* Kp = (bf16_t*)d.prime;
+        bf16_t* Vp = Kp + (int64_t)B * R * D;
+        {   // K'[b, h*T + j, :] = scale * k_h Wq_h
+            XgArgs a{};
+            a.A = (const bf16_t*)d.proj; a.lda = 2 * D; a.a_sb = dh;
+            a.B = (const bf16_t*)d.wq_t; a.ldb = D; a.b_sb = dh;             // Wq^T [c][h dh + d]
+            a.M = B * T; a.N = D; a.K = dh;
+            a.C = Kp; a.ldc = D; a.c_sb = (int64_t)T * D;
+            a.rdiv = T; a.rmul = R;
+            a.alpha = scale;
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            // V'[b, h*T + j, :] = v_h Wo[:, h]^T
+            a.A = (const bf16_t*)d.proj + D;
+            a.B = (const bf16_t*)d.wo; a.ldb = D; a.b_sb = dh;               // Wo [n][h dh + d]
+            a.C = Vp;
+            a.alpha = 1.0f;
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        }
+        {
+            const int n = B * T * H;
+            hipLaunchKernelGGL(xattn_colbias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)d.proj,
+                               (int64_t)2 * D, d.bq, d.key_mask, d.colbias, B, T, H, dh, scale);
+            XCHK(hip_launch_status());
+        }
+        {   // P = softmax over each head's 32 keys of (x K'^T + c)
+            XgArgs a{};
+            a.A = (const bf16_t*)d.x; a.lda = D; a.a_sb = (int64_t)I * D;
+            a.B = Kp; a.ldb = D; a.b_sb = (int64_t)R * D;
+            a.M = I; a.N = R; a.K = D;
+            a.C = (bf16_t*)d.probs; a.ldc = R; a.c_sb = (int64_t)I * R;
+            a.C2 = drop ? (bf16_t*)d.probs_drop : nullptr;
+            a.alpha = 1.0f;
+            a.colbias = d.colbias; a.cb_sb = R;
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+            a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
+        }
+        {   // s = dropout(drop(P) V' + bo) + x
+            XgArgs a{};
+            a.A = (const bf16_t*)(drop ? d.probs_drop : d.probs); a.lda = R; a.a_sb = (int64_t)I * R;
+            a.B = Vp; a.ldb = D; a.b_sb = (int64_t)R * D;
+            a.M = I; a.N = D; a.K = R;
+            a.C = (bf16_t*)d.s; a.ldc = D;
+            a.bias = d.bo;
+            a.residual = (const bf16_t*)d.x;
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
+            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
+        }
+    }
+    // out = LayerNorm(s)                                                          (bert_model.py:363)
+    return m3ae_layernorm_fwd(d.s, d.ln_g, d.ln_b, d.out, d.mean, d.rstd, (int64_t)B * Lq, D, d.ln_eps, M3AE_BF16,
+                              M3AE_ACT_NONE, 0, stream);
+}

@@ -38,6 +38,18 @@ class AttnDesc(C.Structure):
     ]
 
 
+class XattnDesc(C.Structure):
+    _fields_ = [
+        ("dir", i32), ("B", i64), ("Lq", i64), ("Lk", i64), ("D", i64), ("H", i64),
+        ("x", vp), ("y", vp), ("key_mask", vp),
+        ("wq", vp), ("wq_t", vp), ("wkv", vp), ("wkv_t", vp), ("wo", vp), ("wo_t", vp),
+        ("bq", vp), ("bkv", vp), ("bo", vp), ("ln_g", vp), ("ln_b", vp),
+        ("ln_eps", f32), ("dropout_p", f32), ("seed_attn", C.c_uint64), ("seed_hidden", C.c_uint64),
+        ("proj", vp), ("prime", vp), ("colbias", vp), ("probs", vp), ("probs_drop", vp), ("rowsum", vp),
+        ("zctx", vp), ("ctx", vp), ("s", vp), ("out", vp), ("mean", vp), ("rstd", vp),
+    ]
+
+
 _SIGS = {
     "m3ae_abi_version": (C.c_int, []),
     "m3ae_last_gemm_path": (C.c_char_p, []),
@@ -45,6 +57,9 @@ _SIGS = {
     "m3ae_attn_workspace_bytes": (i64, [C.POINTER(AttnDesc), C.c_int]),
     "m3ae_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "m3ae_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "m3ae_xattn_supported": (C.c_int, [C.POINTER(XattnDesc)]),
+    "m3ae_xattn_probs_ld": (i64, [C.POINTER(XattnDesc)]),
+    "m3ae_xattn_fwd": (C.c_int, [C.POINTER(XattnDesc), vp]),
     "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
     "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),

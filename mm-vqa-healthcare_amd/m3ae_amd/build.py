@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(OUT_DIR, "libm3ae_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
-         f"-I{INC}", f"-I{CSRC}"]
+         f"-I{INC}", f"-I{CSRC}"] + os.environ.get("M3AE_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

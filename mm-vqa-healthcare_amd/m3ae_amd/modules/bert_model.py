@@ -62,6 +62,14 @@ class BertAttention(nn.Module):
         """Op-level composition (A/B reference of the fused blocks).  Draws its dropout seeds in the same order as
         ops._attn_sub_fwd, so fused and unfused runs started from one `ops.set_dropout_seed` use identical masks."""
         heads = self.self.num_attention_heads
+        if other is not None and not torch.is_grad_enabled():
+            # inference: the fused sub-block (csrc/xattn.hip) when the shapes are covered
+            B, L, D = h.shape
+            Lo = other.shape[1]
+            P = self.block_params()
+            h2, o2 = h.contiguous().view(B * L, D), other.contiguous().view(B * Lo, other.shape[2])
+            if ops.xattn_supported(h2, L, o2, Lo, other_mask, P):
+                return ops.xattn_fwd(h2, B, L, o2, Lo, other_mask, P, pdrop)[0].view(B, L, D)
         da = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
         dh = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
         if other is None:

@@ -13,7 +13,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, check)
+from ._lib import (ACT_GELU, ACT_MULAUX, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_TANH, BF16, F32, AttnDesc, GemmDesc, XattnDesc,
+                   check)
 
 grad_ready_hook = None  # callable(param) set by the DDP reducer
 # forward activation GEMMs save act'(pre-activation) for their backward GEMM (A/B knob: M3AE_SAVE_DACT=0 saves the
@@ -558,11 +559,84 @@ def _bdata(b):
     return None if b is None else (b.data if hasattr(b, "members") else b.detach())
 
 
-def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
+# the fused cross-attention sub-block (csrc/xattn.hip): "auto" = whenever the shapes are covered (bf16, 32 text tokens,
+# <= 640 image tokens); "off" = always the composition q / kv GEMM + flash attention + output GEMM + LayerNorm
+XATTN = os.environ.get("M3AE_XATTN", "auto")
+
+
+def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):
+    D = h2.shape[1]
+    d = XattnDesc()
+    d.dir = 0 if L <= Lo else 1
+    d.B, d.Lq, d.Lk, d.D, d.H = B, L, Lo, D, P.heads
+    d.x, d.y = h2.data_ptr(), other2.data_ptr()
+    d.key_mask = mask.data_ptr() if mask is not None else None
+    wq, wkv, wo = P.w_q, P.w_kv, P.w_o
+    d.wq, d.wkv, d.wo = compute_weight(wq).data_ptr(), compute_weight(wkv).data_ptr(), compute_weight(wo).data_ptr()
+    d.wq_t, d.wkv_t, d.wo_t = wq.m3ae_t.data_ptr(), wkv.m3ae_t.data_ptr(), wo.m3ae_t.data_ptr()
+    d.bq, d.bkv, d.bo = _bdata(P.b_q).data_ptr(), _bdata(P.b_kv).data_ptr(), _bdata(P.b_o).data_ptr()
+    d.ln_g, d.ln_b, d.ln_eps = P.ln.weight.data_ptr(), P.ln.bias.data_ptr(), P.ln.eps
+    if pdrop > 0:
+        d.dropout_p, d.seed_attn, d.seed_hidden = pdrop, seeds[0], seeds[1]
+    return d
+
+
+def xattn_supported(h2, L, other2, Lo, mask, P):
+    if XATTN == "off" or h2.dtype != torch.bfloat16 or other2.shape[1] != h2.shape[1]:
+        return False
+    if getattr(P.w_q, "m3ae_t", None) is None or getattr(P.w_kv, "m3ae_t", None) is None or getattr(P.w_o, "m3ae_t", None) is None:
+        return False
+    d = XattnDesc()
+    d.dir = 0 if L <= Lo else 1
+    d.B, d.Lq, d.Lk, d.D, d.H = 1, L, Lo, h2.shape[1], P.heads
+    return bool(_lib.lib().m3ae_xattn_supported(C.byref(d)))
+
+
+def xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
+    """BertAttention as crossattention (bert_model.py:480-488) through the fused kernels.  Returns (out, saved)."""
+    _need_cuda(h2)
+    dev, D, H = h2.device, h2.shape[1], P.heads
+    seeds = (next_dropout_seed(), next_dropout_seed()) if pdrop > 0 else None
+    d = _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds)
+    bf = torch.bfloat16
+    T, R = min(L, Lo), H * min(L, Lo)
+    e = lambda *shape, dt=bf: torch.empty(shape, dtype=dt, device=dev)
+    t = {}
+    if d.dir == 0:
+        t["proj"] = e(B * L, D)
+        t["prime"] = e(B, R, D)
+        t["probs"] = e(B, R, 640)
+        t["zctx"] = e(B, R, D)
+        t["ctx"] = e(B * L, D)
+        if pdrop > 0:
+            t["probs_drop"] = e(B, R, 640)
+            t["rowsum"] = e(B, R, dt=torch.float32)
+    else:
+        t["proj"] = e(B * Lo, 2 * D)
+        t["prime"] = e(2, B, R, D)
+        t["colbias"] = e(B, R, dt=torch.float32)
+        t["probs"] = e(B, L, R)
+        if pdrop > 0:
+            t["probs_drop"] = e(B, L, R)
+    t["s"] = e(B * L, D)
+    t["out"] = e(B * L, D)
+    t["mean"] = e(B * L, dt=torch.float32)
+    t["rstd"] = e(B * L, dt=torch.float32)
+    for k, v in t.items():
+        setattr(d, k, v.data_ptr())
+    e0 = _prof_begin()
+    check(_lib.lib().m3ae_xattn_fwd(C.byref(d), _stream()), "m3ae_xattn_fwd")
+    _prof_end(e0, "xattn_fwd", (B, H, L, Lo, D // H))
+    return t["out"], ("xattn", h2, other2, mask, t, seeds, pdrop)
+
+
+def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0, fused_cross=False):
     """BertAttention (bert_model.py:367-413) on 2-D token-major activations. Returns (y, saved).
     pdrop > 0 (training): attention-probability dropout (:334) and hidden dropout on the output dense (:362)."""
     heads = P.heads
     D = h2.shape[1]
+    if other2 is not None and fused_cross and xattn_supported(h2, L, other2, Lo, mask, P):
+        return xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop)
     da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     if other2 is None:
