@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by importing and running the reference's own modules (build container only).
 
-TEST INFRASTRUCTURE ONLY.  Usage:  python oracle/make_golden.py [tiny] [full] [pretrain] [t5] [decoder] [t5gen] [mlm]
+TEST INFRASTRUCTURE ONLY.  Usage:  python oracle/make_golden.py [tiny] [full] [large1] [pretrain] [t5] [decoder] [t5gen] [mlm]
 
 Inputs and weights are NOT stored: they are regenerated bit-identically from
 m3ae_amd.synth (counter-based, keyed by tensor name).  Only the reference's OUTPUTS are stored:
@@ -26,6 +26,16 @@ TINY = dict(image_size=64, hidden_size=128, num_heads=2, num_top_layer=2, input_
             input_text_embed_size=128, vocab_size=1000)
 TINY_ARCH = dict(vision_layers=3, vision_width=128, text_layers=2, text_hidden=128, text_heads=2,
                  text_inter=512, vocab=1000)
+
+
+LARGE1 = dict(image_size=512, num_top_layer=1, input_image_embed_size=1024, input_text_embed_size=1024, vocab_size=1000,
+              vit="ViT-L/16", tokenizer="roberta-large")
+LARGE1_ARCH = dict(vision_layers=2, vision_width=1024, text_layers=1, text_hidden=1024, text_heads=16, text_inter=4096,
+                   vocab=1000)
+
+
+def large1_batch():
+    return synth.synthetic_batch(2, text_len=32, image_size=512, vocab_size=1000, rank=0)
 
 
 def tiny_batch():
@@ -186,6 +196,44 @@ def run_pretrain():
     labels = torch.tensor([1, 0])
     res["itm_logits"] = il.detach().numpy()
     res["itm_loss"] = np.float64(F.cross_entropy(il, labels).item())
+    # one full pre-training step (objectives.py:14-119 summed, as M3AETransformerSS.training_step does): MLM + MIM + ITM
+    # with the ITM negatives SWAPPED IN by the reference's own selection rule (objectives.py:85-93: ti if label == 1
+    # else fi) for labels [1, 0]; gradients of every parameter -> per-parameter norms
+    m.zero_grad()
+    inf = m.infer(batch, mask_text=True, mask_image=False)
+    logits = m.mlm_head(inf["multi_modal_text_feats"])
+    l_mlm = F.cross_entropy(logits.view(-1, cfg["vocab_size"]), inf["text_labels"].view(-1), ignore_index=-100)
+    torch.rand = lambda *a, **k: noise.clone()
+    try:
+        inf = m.infer(batch, mask_text=False, mask_image=True)
+    finally:
+        torch.rand = real_rand
+    pred = m.mim_head(inf[f"multi_modal_image_feats_{cfg['mim_layer']}"], inf["mim_ids_restore"])
+    target = inf["patched_images"]
+    target = (target - target.mean(dim=-1, keepdim=True)) / (target.var(dim=-1, keepdim=True) + 1.e-6) ** .5
+    mask = inf["mim_masks"]
+    l_mim = (((pred - target) ** 2).mean(dim=-1) * mask).sum() / mask.sum()
+    itm_labels = torch.tensor([1.0, 0.0])
+    itm_images = [torch.stack([ti if itm_labels[i] == 1 else fi for i, (ti, fi) in enumerate(zip(bti, bfi))])
+                  for bti, bfi in zip(batch["image"], batch["false_image_0"])]
+    b2 = {k: v for k, v in batch.items()}
+    b2["image"] = itm_images
+    inf = m.infer(b2, mask_text=False, mask_image=False)
+    il = m.itm_head(inf["multi_modal_cls_feats"])
+    l_itm = F.cross_entropy(il, itm_labels.long())
+    res["itm_swapped_logits"] = il.detach().numpy()
+    res["itm_swapped_loss"] = np.float64(l_itm.item())
+    total = l_mlm + l_mim + l_itm
+    total.backward()
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(p.grad.double().norm().item())
+    res["step_loss"] = np.float64(total.item())
+    res["grad_names"] = np.array(names)
+    res["grad_norm"] = np.array(norms, dtype=np.float64)
+    res["global_grad_norm"] = np.float64(np.sqrt((np.array(norms) ** 2).sum()))
     np.savez_compressed(os.path.join(GOLD, "tiny_pretrain.npz"), **res)
     print("[pretrain] mlm", res["mlm_loss"], "mim", res["mim_loss"], "itm", res["itm_loss"])
 
@@ -429,7 +477,7 @@ def run_mlm_collate():
 
 
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "pretrain", "t5", "decoder", "t5gen", "mlm"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "decoder", "t5gen", "mlm"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -445,6 +493,10 @@ def main():
         run_mlm_collate()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
+    if "large1" in what:
+        # configs[4]'s tower dimensions at reduced depth: ONE ViT-L/16 block (width 1024, 16 heads, 512 x 512 = 1025 image
+        # tokens), ONE RoBERTa-large layer (1024 / 16 heads / 4096), ONE co-attention layer pair (768 / 12 heads)
+        run_vqa("large1_vqa", rs.reference_config(**LARGE1), LARGE1_ARCH, large1_batch(), "stat")
 
 
 if __name__ == "__main__":

@@ -41,6 +41,21 @@ def full_batch(B=2):
     return synth.synthetic_batch(B, text_len=32, image_size=384, vocab_size=50265, rank=0)
 
 
+def large1_config(**over):
+    """configs[4] tower dimensions at reduced depth (oracle/make_golden.py LARGE1): one ViT-L/16 block (width 1024, 16 heads,
+    512 x 512 -> 1025 tokens), one RoBERTa-large layer, one co-attention layer pair."""
+    from m3ae_amd.config import compose
+    base = dict(image_size=512, num_top_layer=1, input_image_embed_size=1024, input_text_embed_size=1024, vocab_size=1000,
+                vit="ViT-L/16", tokenizer="roberta-large", vit_width=1024, vit_layers=2, text_hidden=1024, text_layers=1,
+                text_heads=16, text_inter=4096)
+    base.update(over)
+    return compose("task_finetune_vqa_vqa_rad", "clip16", "text_roberta", **base)
+
+
+def large1_batch():
+    return synth.synthetic_batch(2, text_len=32, image_size=512, vocab_size=1000, rank=0)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)
 

@@ -68,6 +68,51 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     _lib.lib().m3ae_set_tuning(0, -1)
 
 
+@pytest.mark.parametrize("variant", [7, 8, -1])
+@pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul", "dropout+res"])
+def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant, kind):
+    """The step's dominant kernel -- gemm_nt_pp_kernel (7) and its persistent form (8; what the auto rule (-1) picks from
+    512 tiles on) -- against an INDEPENDENT fp32 torch reference on the same bf16-rounded operands, every epilogue class,
+    at a ragged shape with >= 512 tiles (36965 x 3072 x 768: 145 x 12 = 1740 tiles, last row tile 101 rows)."""
+    from m3ae_amd import _lib
+    L = _lib.lib()
+    M, N, K = 36965, 3072, 768
+    x, w = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=32)
+    b = rnd(N, seed=33)
+    aux = rnd(M, N, dtype=torch.bfloat16, seed=34)
+    pre = x.float() @ w.float().t()
+    L.m3ae_set_tuning(0, variant)
+    try:
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        extra = None
+        if kind == "plain":
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K)
+            ref = pre
+        elif kind == "bias+res":
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, residual=aux)
+            ref = pre + b + aux.float()
+        elif kind == "gelu+deriv":
+            extra = torch.empty_like(y)
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, act=ops.ACT_GELU, preact=extra, preact_grad=True)
+            u = (pre + b).double()
+            ref = torch.nn.functional.gelu(u).float()
+            cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+            dref = (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)).float()
+            close(extra, dref, 1e-2, 1e-2, msg="gelu derivative")
+        elif kind == "dmul":
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_MULAUX)
+            ref = pre * aux.float()
+        else:
+            keep = ops.dropout_keep_mask(M, N, 0.1, 4242)   # the exported mask of (p, seed) on an [M, N] array
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, residual=aux, dropout=(0.1, 4242))
+            ref = (pre + b) * keep.float() / 0.9 + aux.float()
+            assert 0.88 < keep.float().mean().item() < 0.92
+        assert ops.last_gemm_path() == "mfma_nt_pp"
+        close(y, ref, 1e-2, 2e-2, msg=f"variant {variant} {kind}")
+    finally:
+        L.m3ae_set_tuning(0, -1)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (577 * 2, 768, 768), (1000, 2304, 768), (4616, 768, 3072), (37, 128, 256),
                                    (4616, 256, 512), (9000, 768, 768)])
 def test_gemm_wgrad_tn(M, N, K):

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import m3ae_oracle as O
-from oracle_util import (full_batch, finetune_vqa_rad_config, load_golden, make_sd, oracle_cfg, tiny_batch, tiny_config)
+from oracle_util import (large1_batch, large1_config, full_batch, finetune_vqa_rad_config, load_golden, make_sd, oracle_cfg, tiny_batch, tiny_config)
 
 
 def _grad_check(sd, g, rtol=2e-4):
@@ -65,6 +65,29 @@ def test_tiny_pretrain_heads_match_reference():
     out = O.infer(sd, oc, img, b["text_ids"], b["text_masks"])
     il = O.itm_head(sd, out["multi_modal_cls_feats"])
     np.testing.assert_allclose(il.numpy(), g["itm_logits"], rtol=1e-4, atol=1e-6)
+    # the whole pre-training step with the ITM negatives swapped in for labels [1, 0] (objectives.py:85-93): loss and the
+    # per-parameter gradient norms of the reference
+    for p in sd.values():
+        p.requires_grad_(p.dtype.is_floating_point)
+    sd["mim_head.decoder_pos_embed"].requires_grad_(False)
+    o1 = O.infer(sd, oc, img, b["text_ids_mlm"], b["text_masks"])
+    l_mlm = O.mlm_loss(O.mlm_head(sd, o1["multi_modal_text_feats"]), b["text_labels_mlm"])
+    o2 = O.infer(sd, oc, img, b["text_ids"], b["text_masks"], mim_noise=b["mim_noise"])
+    l_mim = O.mim_loss(O.mim_head(sd, o2["multi_modal_image_feats_1"], o2["mim_ids_restore"], 2), img, o2["mim_masks"], 16)
+    lab = torch.tensor([1, 0])
+    img_itm = torch.where(lab.view(2, 1, 1, 1).bool(), img, b["false_image_0"][0])
+    o3 = O.infer(sd, oc, img_itm, b["text_ids"], b["text_masks"])
+    il = O.itm_head(sd, o3["multi_modal_cls_feats"])
+    np.testing.assert_allclose(il.detach().numpy(), g["itm_swapped_logits"], rtol=1e-4, atol=1e-6)
+    l_itm = torch.nn.functional.cross_entropy(il, lab)
+    assert abs(l_itm.item() - float(g["itm_swapped_loss"])) < 1e-5
+    total = l_mlm + l_mim + l_itm
+    assert abs(total.item() - float(g["step_loss"])) < 1e-5 * float(g["step_loss"])
+    total.backward()
+    gn = float(g["global_grad_norm"])
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = sd[n].grad.double().norm().item()
+        assert abs(mine - r) < 2e-3 * r + 1e-6 * gn, (n, mine, r)
 
 
 def test_param_groups_and_schedule_match_reference():
@@ -90,6 +113,21 @@ def test_full_size_forward_backward_matches_reference():
     g = load_golden("full_vqa.npz")
     loss, logits, out = O.training_loss(sd, oracle_cfg(cfg), full_batch())
     np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-5)  # north_star tolerance
+    np.testing.assert_allclose(out["multi_modal_cls_feats"].detach().numpy(), g["cls_feats"], rtol=1e-3, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    _grad_check(sd, g, rtol=1e-3)
+
+
+def test_large_tower_dims_reduced_depth_matches_reference():
+    """configs[4] tower dimensions (ViT-L/16: width 1024, 16 heads, 512 x 512 = 1025 tokens; RoBERTa-large: 1024 / 16 /
+    4096) at depth one + one co-attention layer pair, B = 2, fp32, CPU: the oracle against the reference fixture."""
+    torch.set_num_threads(8)
+    cfg = large1_config()
+    sd = make_sd(cfg, requires_grad=True)
+    g = load_golden("large1_vqa.npz")
+    loss, logits, out = O.training_loss(sd, oracle_cfg(cfg), large1_batch())
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(out["multi_modal_cls_feats"].detach().numpy(), g["cls_feats"], rtol=1e-3, atol=1e-5)
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
     loss.backward()
