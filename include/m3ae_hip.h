@@ -76,7 +76,11 @@ typedef struct {
     int32_t preact_grad;   /* forward: store act'(pre-activation) in `preact` instead of the pre-activation: the erf / exp
                             * terms are already in registers there, and the backward GEMM (dact = M3AE_ACT_MULAUX) then
                             * multiplies by the saved derivative instead of re-evaluating it (its epilogue was VALU-bound) */
+    int32_t launch_flags;  /* M3AE_GEMM_NO_PERSISTENT: never take the persistent (one workgroup per CU, static tile lists)
+                            * form of the NT kernel -- for callers that run collectives next to the GEMMs (RCCL kernels
+                            * hold CUs; a persistent workgroup that finds none starts after another has walked its list) */
 } m3ae_gemm_desc;
+enum { M3AE_GEMM_NO_PERSISTENT = 1 };
 int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -277,11 +281,12 @@ int m3ae_mim_loss_fwd(const void* x, const float* target, const float* mask, flo
 int m3ae_mim_loss_bwd(const void* x, const float* target, const float* mask, const float* acc, const float* gout, void* dx,
                       int64_t B, int64_t L, int64_t D, int dtype, void* stream);
 
-/* tuning knobs for A/B measurements (process-global, not part of the data path contract).
+/* DIAGNOSTIC knobs for A/B measurements of the GEMM kernels (tools/, tests): process-global, not part of the data path
+ * contract -- the product path (m3ae_amd/) never calls this; launch policy that callers need is per call
+ * (m3ae_gemm_desc.launch_flags).
  * key 0: NT GEMM kernel (-1 = auto by shape; 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its
  *        persistent form, 9 = dual kernel: 128x256 tiles, two workgroups per CU);
  * key 1: TN (wgrad) kernel (-1 = auto by shape; 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong);
- * key 2: attention kernel family (cooperative / per-wave);
  * key 4: dual NT kernel, start-up delay of a CU's second workgroup in 100-MHz ticks (-1 = from K);
  * key 5: dual NT kernel, 1 = every workgroup overwrites 28 B of its tile with (HW_ID, XCC_ID, start, main-loop end,
  *        epilogue end, launch index, shader clocks) -- DIAGNOSTIC, corrupts C (tools/nt_trace.py);

@@ -216,335 +216,6 @@ DEVINL void score_to_prob(f32x16& s, float& m, float& l, f32x16& o0, f32x16& o1,
     }
 }
 
-template <int NQ, bool MASK, bool BIAS, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnArgs a) {
-    // wave = NQ x 32 query rows; streams 32-key tiles
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
-    const int head = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int64_t q0 = qt * (32 * NQ);
-    if (q0 >= a.Lq) return;  // whole wave; no barriers in this kernel
-    char* tile = lds + wave * TILE_LDS;
-
-    int64_t qi[NQ];
-    s16x8 qf[NQ][4];
-    const float* brow[NQ];
-    f32x16 o[NQ][2];
-    float m[NQ], l[NQ];
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        qi[n] = q0 + 32 * n + r;
-        const int64_t qrow = qi[n] < a.Lq ? qi[n] : a.Lq - 1;
-        const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[n][ks] = row_frag(qp, ks, h);
-        brow[n] = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
-        o[n][0] = zero16(); o[n][1] = zero16();
-        m[n] = -1e30f; l[n] = 0.f;
-    }
-    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
-    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
-    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
-    const int nkt = (int)((a.Lk + 31) / 32);
-
-    const TileOffs ko = make_offs(lane, a.k_sl), vo = make_offs(lane, a.v_sl);
-    s16x8 kf_n[4];
-    {
-        const int64_t kr = r < a.Lk ? r : a.Lk - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-    }
-    Stage4 vs_n = tile_load(vbase, a.v_sl, 0, a.Lk, lane);
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        s16x8 kf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks] = kf_n[ks];
-        asm volatile("" ::: "memory");
-        tile_store(tile, vs_n, lane);
-        const bool last = kt + 1 == nkt;
-        if (!last) {
-            const int64_t row0 = (int64_t)(kt + 1) * 32;
-            if (row0 + 32 <= a.Lk) {  // full tile: uniform base + lane offsets
-                const bf16_t* kt_base = kbase + row0 * a.k_sl;
-                const bf16_t* vt_base = vbase + row0 * a.v_sl;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag_u(kt_base, ko, ks);
-                vs_n = tile_load_u(vt_base, vo);
-            } else {
-                int64_t kr = row0 + r;
-                kr = kr < a.Lk ? kr : a.Lk - 1;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-                vs_n = tile_load(vbase, a.v_sl, row0, a.Lk, lane);
-            }
-        }
-        f32x16 s[NQ];
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            s[n] = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[n] = mfma32(kf[ks], qf[n][ks], s[n]);  // S^T[key][q] = K . Q^T
-        }
-        const int64_t key0 = (int64_t)kt * 32;
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            if (last) score_to_prob<MASK, BIAS, CAUSAL, true>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
-            else score_to_prob<MASK, BIAS, CAUSAL, false>(s[n], m[n], l[n], o[n][0], o[n][1], a, mrow, brow[n], key0, qi[n], h);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's V tile is in LDS
-        // O^T[d][q] += V^T[d][key] . P^T[key][q]
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            const s16x8 v0 = tr_frag(tile, 0, ss, lane), v1 = tr_frag(tile, 1, ss, lane);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const s16x8 pb = pack_acc(s[n], ss);
-                o[n][0] = mfma32(v0, pb, o[n][0]);
-                o[n][1] = mfma32(v1, pb, o[n][1]);
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const float ltot = l[n] + __shfl_xor(l[n], 32, 64);
-        if (qi[n] < a.Lq) {
-            store_rows(a.o + b * a.o_sb + qi[n] * a.o_sl + head * 64, o[n][0], o[n][1], 1.0f / ltot, h);
-            if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi[n]] = m[n] + log2f(ltot);
-        }
-    }
-}
-
-// delta[b][h][q] = sum_d dO . O
-__global__ void attn_delta_kernel(AttnArgs a) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = a.B * a.Lq * a.H;
-    if (idx >= total) return;
-    const int head = (int)(idx % a.H);
-    const int64_t q = (idx / a.H) % a.Lq, b = idx / (a.H * a.Lq);
-    const bf16_t* op = a.o + b * a.o_sb + q * a.o_sl + head * 64;
-    const bf16_t* dp = a.d_o + b * a.o_sb + q * a.o_sl + head * 64;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const s16x8 x = *(const s16x8*)(op + 8 * c), y = *(const s16x8*)(dp + 8 * c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)x[j]) * bf2f((bf16_t)y[j]);
-    }
-    a.delta[(b * a.H + head) * a.lse_stride + q] = acc;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// backward: dQ   (wave = 32 queries, streams key tiles)
-// ---------------------------------------------------------------------------------------------------------
-template <bool MASK, bool BIAS, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_LDS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
-    const int head = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int64_t q0 = qt * 32;
-    if (q0 >= a.Lq) return;
-    char* tile = lds + wave * TILE_LDS;
-
-    const int64_t qi = q0 + r;
-    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
-    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
-    const bf16_t* dop = a.d_o + b * a.o_sb + qrow * a.o_sl + head * 64;
-    s16x8 qf[4], dof[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(qp, ks, h); dof[ks] = row_frag(dop, ks, h); }
-    const float lse = a.lse[(b * a.H + head) * a.lse_stride + qrow];
-    const float dlt = a.delta[(b * a.H + head) * a.lse_stride + qrow];
-
-    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
-    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
-    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
-    const float* brow = BIAS ? a.pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
-    float* dbrow = (BIAS && a.d_pos_bias) ? a.d_pos_bias + ((int64_t)head * a.Lq + qrow) * a.Lk : nullptr;
-
-    f32x16 g0 = zero16(), g1 = zero16();
-    const int nkt = (int)((a.Lk + 31) / 32);
-    const TileOffs ko = make_offs(lane, a.k_sl), vo = make_offs(lane, a.v_sl);
-    s16x8 kf_n[4], vf_n[4];
-    {
-        const int64_t kr = r < a.Lk ? r : a.Lk - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-            vf_n[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
-        }
-    }
-    Stage4 kst_n = tile_load(kbase, a.k_sl, 0, a.Lk, lane);
-    for (int kt = 0; kt < nkt; ++kt) {
-        s16x8 kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kf_n[ks]; vf[ks] = vf_n[ks]; }
-        asm volatile("" ::: "memory");
-        tile_store(tile, kst_n, lane);
-        const bool last = kt + 1 == nkt;
-        if (!last) {
-            const int64_t row0 = (int64_t)(kt + 1) * 32;
-            if (row0 + 32 <= a.Lk) {
-                const bf16_t* kt_base = kbase + row0 * a.k_sl;
-                const bf16_t* vt_base = vbase + row0 * a.v_sl;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    kf_n[ks] = row_frag_u(kt_base, ko, ks);
-                    vf_n[ks] = row_frag_u(vt_base, vo, ks);
-                }
-                kst_n = tile_load_u(kt_base, ko);
-            } else {
-                int64_t kr = row0 + r;
-                kr = kr < a.Lk ? kr : a.Lk - 1;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    kf_n[ks] = row_frag(kbase + kr * a.k_sl, ks, h);
-                    vf_n[ks] = row_frag(vbase + kr * a.v_sl, ks, h);
-                }
-                kst_n = tile_load(kbase, a.k_sl, row0, a.Lk, lane);
-            }
-        }
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t key = (int64_t)kt * 32 + crow(reg, h);
-            float x = s[reg] * a.scale_log2;
-            bool valid = true;
-            if (MASK || BIAS || last) {
-                const int64_t kc = key < a.Lk ? key : a.Lk - 1;
-                if (MASK) x = fmaf(mrow[kc], LOG2E, x);
-                if (BIAS) x = fmaf(brow[kc], LOG2E, x);
-                valid = key < a.Lk;
-            }
-            if (CAUSAL) valid = valid && key <= qi;
-            const float p = valid ? fast_exp2(x - lse) : 0.f;
-            const float ds = p * (dp[reg] - dlt);
-            if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
-            s[reg] = ds;
-        }
-        const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-        g0 = mfma32(tr_frag(tile, 0, 0, lane), d0, g0);
-        g1 = mfma32(tr_frag(tile, 1, 0, lane), d0, g1);
-        g0 = mfma32(tr_frag(tile, 0, 1, lane), d1, g0);
-        g1 = mfma32(tr_frag(tile, 1, 1, lane), d1, g1);
-    }
-    if (qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// backward: dK, dV   (wave = 32 keys, streams query tiles)
-// ---------------------------------------------------------------------------------------------------------
-template <bool MASK, bool BIAS, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[8 * TILE_LDS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t kt = (int64_t)blockIdx.x * 4 + wave;
-    const int head = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int64_t k0 = kt * 32;
-    if (k0 >= a.Lk) return;
-    char* qtile = lds + wave * 2 * TILE_LDS;
-    char* dotile = qtile + TILE_LDS;
-
-    const int64_t ki = k0 + r;
-    const int64_t krow = ki < a.Lk ? ki : a.Lk - 1;
-    const bf16_t* kp = a.k + b * a.k_sb + krow * a.k_sl + head * 64;
-    const bf16_t* vp = a.v + b * a.v_sb + krow * a.v_sl + head * 64;
-    s16x8 kfb[4], vfb[4];  // B operands: K^T[d][key], V^T[d][key]
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { kfb[ks] = row_frag(kp, ks, h); vfb[ks] = row_frag(vp, ks, h); }
-    const float mk = MASK ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
-    const bool key_ok = ki < a.Lk;
-
-    const bf16_t* qbase = a.q + b * a.q_sb + head * 64;
-    const bf16_t* dobase = a.d_o + b * a.o_sb + head * 64;
-    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;    // 128-B aligned, padded to a multiple of 32
-    const float* drow = a.delta + (b * a.H + head) * a.lse_stride;
-    const float* bcol = BIAS ? a.pos_bias + (int64_t)head * a.Lq * a.Lk + krow : nullptr;
-
-    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-    const int nqt = (int)((a.Lq + 31) / 32);
-    const TileOffs qo = make_offs(lane, a.q_sl), doo = make_offs(lane, a.o_sl);
-    Stage4 qs_n = tile_load(qbase, a.q_sl, 0, a.Lq, lane);
-    Stage4 dos_n = tile_load(dobase, a.o_sl, 0, a.Lq, lane);
-    for (int qt = 0; qt < nqt; ++qt) {
-        asm volatile("" ::: "memory");
-        tile_store(qtile, qs_n, lane);
-        tile_store(dotile, dos_n, lane);
-        const bool last = qt + 1 == nqt;
-        if (!last) {
-            const int64_t row0 = (int64_t)(qt + 1) * 32;
-            if (row0 + 32 <= a.Lq) {
-                qs_n = tile_load_u(qbase + row0 * a.q_sl, qo);
-                dos_n = tile_load_u(dobase + row0 * a.o_sl, doo);
-            } else {
-                qs_n = tile_load(qbase, a.q_sl, row0, a.Lq, lane);
-                dos_n = tile_load(dobase, a.o_sl, row0, a.Lq, lane);
-            }
-        }
-        // per-row softmax statistics of this q tile: rows crow(reg, h) -> 4 aligned float4 groups
-        f32x4 lse4[4], dl4[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            lse4[g4] = *(const f32x4*)(lrow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
-            dl4[g4] = *(const f32x4*)(drow + (int64_t)qt * 32 + 8 * g4 + 4 * h);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's Q / dO tiles are in LDS
-        s16x8 qfa[4], dofa[4];  // A operands: Q[q][d], dO[q][d] (row reads of the staged tiles)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { qfa[ks] = lds_row_frag(qtile, r, ks, h); dofa[ks] = lds_row_frag(dotile, r, ks, h); }
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S[q][key]
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP[q][key] = dO . V^T
-        f32x16 p;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
-            bool valid = key_ok;
-            if (last) valid = valid && qq < a.Lq;
-            if (CAUSAL) valid = valid && ki <= qq;
-            float x = fmaf(s[reg], a.scale_log2, mk);
-            if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
-            const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
-            p[reg] = pv;
-            s[reg] = pv * (dp[reg] - dl4[reg >> 2][reg & 3]);
-        }
-        const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
-        const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
-        // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
-        dv0 = mfma32(tr_frag(dotile, 0, 0, lane), p0, dv0);
-        dv1 = mfma32(tr_frag(dotile, 1, 0, lane), p0, dv1);
-        dv0 = mfma32(tr_frag(dotile, 0, 1, lane), p1, dv0);
-        dv1 = mfma32(tr_frag(dotile, 1, 1, lane), p1, dv1);
-        dk0 = mfma32(tr_frag(qtile, 0, 0, lane), d0, dk0);
-        dk1 = mfma32(tr_frag(qtile, 1, 0, lane), d0, dk1);
-        dk0 = mfma32(tr_frag(qtile, 0, 1, lane), d1, dk0);
-        dk1 = mfma32(tr_frag(qtile, 1, 1, lane), d1, dk1);
-    }
-    if (key_ok) {
-        store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
-        store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
-    }
-}
-
 // =========================================================================================================
 // Workgroup-cooperative variants ("coop"): the 4 waves of a workgroup own consecutive row tiles of ONE (batch, head)
 // and share every streamed tile through LDS: one coalesced 16-B-per-lane global load per tile for the whole
@@ -991,21 +662,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     } while (0)
 
 // flag dispatch (mask / bias / causal are wave-uniform launch properties)
-#define ATTN_DISPATCH3(KERNEL, grid, s, a, ...)                                                                       \
-    do {                                                                                                             \
-        const int f = (a.key_mask ? 1 : 0) | (a.pos_bias ? 2 : 0) | (a.causal ? 4 : 0);                              \
-        switch (f) {                                                                                                 \
-            case 0: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, false>), grid, dim3(256), 0, s, a); break;  \
-            case 1: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, false>), grid, dim3(256), 0, s, a); break;   \
-            case 2: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, false>), grid, dim3(256), 0, s, a); break;   \
-            case 3: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, false>), grid, dim3(256), 0, s, a); break;    \
-            case 4: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, false, true>), grid, dim3(256), 0, s, a); break;   \
-            case 5: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false, true>), grid, dim3(256), 0, s, a); break;    \
-            case 6: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true, true>), grid, dim3(256), 0, s, a); break;    \
-            default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true, true>), grid, dim3(256), 0, s, a); break;    \
-        }                                                                                                            \
-    } while (0)
-
 // ---------------------------------------------------------------------------------------------------------
 // fp32 reference-shaped path: row softmax kernels over the materialised score matrix
 // ---------------------------------------------------------------------------------------------------------
@@ -1114,11 +770,6 @@ bool bf16_layout_ok(const m3ae_attn_desc& d, bool bwd) {
 
 }  // namespace
 
-static int g_attn_coop = getenv("M3AE_ATTN_COOP") ? atoi(getenv("M3AE_ATTN_COOP")) : 1;
-// 1 (default): 32 query rows per wave everywhere (577 = 18 x 32 + 1: finer blocks waste less, occupancy 4: 188 -> 135 us
-// at B = 64); 2: 64 rows per wave on long sequences
-static int g_attn_nq = getenv("M3AE_ATTN_NQ") ? atoi(getenv("M3AE_ATTN_NQ")) : 1;
-int m3ae_attn_set_coop(int v) { g_attn_coop = v; return 0; }
 
 extern "C" int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward) {
     if (!d) return 0;
@@ -1136,25 +787,12 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
         if (!bf16_layout_ok(d, false)) return M3AE_ERR_UNSUPPORTED;
         if (d.H > 65535 || d.B > 65535) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
-        if (g_attn_coop || a.has_drop) {
-            int rc = 0;
-            if (d.Lq > 32 && d.Lk > 64 && g_attn_nq != 1) {
-                dim3 grid((unsigned)cdiv(d.Lq, 256), (unsigned)d.H, (unsigned)d.B);
-                ATTN_DISPATCH_COOP(rc, attn_fwd_coop_kernel, grid, s, a, 2, );
-            } else {
-                dim3 grid((unsigned)cdiv(d.Lq, 128), (unsigned)d.H, (unsigned)d.B);
-                ATTN_DISPATCH_COOP(rc, attn_fwd_coop_kernel, grid, s, a, 1, );
-            }
-            if (rc) return rc;
-            return hip_launch_status();
-        }
-        if (d.Lq > 32 && d.Lk > 64) {  // 64 query rows per wave: K / V fragments are fetched once for two query blocks
-            dim3 grid((unsigned)cdiv(cdiv(d.Lq, 64), 4), (unsigned)d.H, (unsigned)d.B);
-            ATTN_DISPATCH3(attn_fwd_bf16_kernel, grid, s, a, 2, );
-        } else {
-            dim3 grid((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
-            ATTN_DISPATCH3(attn_fwd_bf16_kernel, grid, s, a, 1, );
-        }
+        // 32 query rows per wave everywhere (577 = 18 x 32 + 1: finer blocks waste less, occupancy 4: 188 -> 135 us at B = 64
+        // against 64 rows per wave on the long sequences)
+        int rc = 0;
+        dim3 grid((unsigned)cdiv(d.Lq, 128), (unsigned)d.H, (unsigned)d.B);
+        ATTN_DISPATCH_COOP(rc, attn_fwd_coop_kernel, grid, s, a, 1, );
+        if (rc) return rc;
         return hip_launch_status();
     }
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;
@@ -1182,21 +820,12 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     if (d.dtype == M3AE_BF16) {
         if (!bf16_layout_ok(d, true)) return M3AE_ERR_UNSUPPORTED;
         AttnArgs a = to_args(d);
-        const int64_t total = d.B * d.Lq * d.H;
-        const bool coop = g_attn_coop || a.has_drop;
-        if (!coop)  // the cooperative dQ kernel computes (and publishes) delta itself
-            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, a);
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
-        if (coop) {
-            int rc = 0;
-            ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );
-            ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
-            if (rc) return rc;
-        } else {
-            ATTN_DISPATCH3(attn_bwd_dq_bf16_kernel, gq, s, a, );
-            ATTN_DISPATCH3(attn_bwd_dkdv_bf16_kernel, gk, s, a, );
-        }
+        int rc = 0;
+        ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );   // also computes (and publishes) delta = rowsum(dO * O)
+        ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
+        if (rc) return rc;
         return hip_launch_status();
     }
     if (d.dtype != M3AE_F32) return M3AE_ERR_UNSUPPORTED;

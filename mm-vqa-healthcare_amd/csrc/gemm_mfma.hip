@@ -48,6 +48,7 @@ struct MfmaArgs {
     int splits;       // TN only
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
     int col_group;      // ping-pong NT kernels: column tiles per group of the tile order (nt_tile_coords)
+    int no_persist;     // desc.launch_flags & M3AE_GEMM_NO_PERSISTENT
     int trace;          // dual NT kernel: overwrite 28 B of every tile's first row with (hw_id, xcc_id, t0, t1, t2, block, clocks)
     int stagger_ticks;  // dual NT kernel: start-up delay of the second workgroup of every CU (100-MHz ticks)
 };
@@ -482,7 +483,6 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int m3ae_attn_set_coop(int v);
 static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : -1;
 static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
 // persistent form of the ping-pong kernel (static tile lists, one workgroup per CU): OFF for data-parallel runs
@@ -500,7 +500,6 @@ extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 6) { g_nt_persist = value; return 0; }
     if (key == 7) { g_nt_col_group = value; return 0; }
     if (key == 1) { g_tn_variant = value; return 0; }
-    if (key == 2) return m3ae_attn_set_coop(value);
     return M3AE_ERR_ARG;
 }
 
@@ -995,7 +994,7 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const double eff128 = (double)t128 / (double)(cdiv(t128, 512) * 512);
         const bool big = a.M > 128 && a.N > 128 && eff256 >= 0.88 * eff128;
         const bool persist_ok = t256 >= 512;   // the persistent form pays from two full rounds on (+1..3 %)
-        if (big && persist_ok && g_nt_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
+        if (big && persist_ok && g_nt_persist && !a.no_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
@@ -1028,6 +1027,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     }
     a.has_drop = d.dropout_p > 0.f;
     a.drop = make_drop(d.dropout_p, d.dropout_seed);
+    a.no_persist = (d.launch_flags & M3AE_GEMM_NO_PERSISTENT) ? 1 : 0;
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
     if (!has_dact && d.act == M3AE_ACT_RELU) return launch_nt_v<EPI_RELU>(a, s);                       // dropout allowed

@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
         ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
         ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
         ("dact_aux", vp), ("dact", i32), ("force_generic", i32), ("a_rowsum", vp),
-        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("preact_grad", i32),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("preact_grad", i32), ("launch_flags", i32),
     ]
 
 

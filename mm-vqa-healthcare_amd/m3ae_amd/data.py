@@ -251,8 +251,11 @@ def finish_batch(db):
     u8 = db.pop("_u8")
     db["image"] = [normalize_on_device(u8)]
     db["text_labels"] = torch.full_like(db["text_ids"], -100)
-    for t in (u8, db["text_ids"], db["text_masks"]):
-        t.record_stream(torch.cuda.current_stream())
+    cur = torch.cuda.current_stream()
+    u8.record_stream(cur)
+    for t in db.values():   # every tensor uploaded on the copy stream (text_ids_mlm / text_labels_mlm included) is now used here
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)
     return db
 
 

@@ -23,9 +23,12 @@ from . import ops
 
 
 class FlatGradReducer:
-    def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True):
+    def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True, collective=None, world=None):
+        """`collective(tensor) -> handle with .wait()` replaces `dist.all_reduce(SUM, async)` (tests: a summing stand-in
+        that plays the other ranks); `world` then names the emulated world size."""
         self.store, self.group, self.overlap = store, group, overlap
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = collective
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         n = store.trainable_end
         per = max(1, bucket_bytes // 4)
         # bucket boundaries on parameter boundaries
@@ -76,11 +79,12 @@ class FlatGradReducer:
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
-        if self.world > 1 and torch.cuda.is_available():
+        if self.world > 1:
             # RCCL's kernels run next to backward and hold some CUs: the persistent NT kernel (static tile lists, one
-            # workgroup per CU) would wait for them with a whole tile list in hand; use the one-tile-per-workgroup launch
-            from . import _lib
-            _lib.lib().m3ae_set_tuning(6, 0)
+            # workgroup per CU) would wait for them with a whole tile list in hand; every GEMM descriptor issued while the
+            # reducer is attached asks for the one-tile-per-workgroup launch (restored by detach())
+            self._saved_no_persist = ops.NT_NO_PERSISTENT
+            ops.NT_NO_PERSISTENT = True
         if self.world > 1 and not self._hooks:
             # a gradient that autograd itself accumulates (glue ops around the kernels, e.g. `x + positional_embedding`
             # in the masked-image pass) arrives at a time the kernels' reports say nothing about: such parameters keep
@@ -102,6 +106,8 @@ class FlatGradReducer:
 
     def detach(self):
         ops.grad_ready_hook = None
+        if getattr(self, "_saved_no_persist", None) is not None:
+            ops.NT_NO_PERSISTENT, self._saved_no_persist = self._saved_no_persist, None
         for h in self._hooks:
             h.remove()
         self._hooks = []
@@ -112,7 +118,10 @@ class FlatGradReducer:
         self.launched[bi] = True
         a, b = self.bounds[bi], self.bounds[bi + 1]
         if b > a:
-            h = dist.all_reduce(self.store.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.collective is not None:
+                h = self.collective(self.store.grad[a:b])
+            else:
+                h = dist.all_reduce(self.store.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append(h)
 
     def on_grad_ready(self, p):
@@ -134,13 +143,23 @@ class FlatGradReducer:
 
     def finish(self):
         """After backward: reduce every bucket not yet launched, wait for all, re-arm for the next step."""
+        late_any = self.late is not None
         if self.world > 1:
             for bi in range(self.nb):
                 self._launch(bi)
+            if self.collective is None:
+                # the error below must be raised on EVERY rank or on none: a rank that raises alone leaves the others
+                # waiting in their next collective.  One more (4-byte) all-reduce in the same queue as the buckets.
+                flag = torch.tensor([1.0 if late_any else 0.0], device=self.store.grad.device)
+                self.handles.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
             for h in self.handles:
-                h.wait()
-        if self.late is not None:
-            name, self.late = self.late, None
+                if h is not None:
+                    h.wait()
+            if self.collective is None:
+                late_any = flag.item() > 0
+        if late_any:
+            name, self.late = self.late or "<on another rank>", None
+            self.reset()
             raise RuntimeError(f"gradient of {name!r} was accumulated after its bucket had been all-reduced (more "
                                "contributions than on the reducer's first step): call reducer.relearn() when the set of "
                                "objectives changes")

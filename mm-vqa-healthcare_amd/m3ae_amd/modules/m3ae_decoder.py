@@ -285,4 +285,5 @@ class DecoderModel(_Base):
 
     def configure_optimizers(self):
         """m3ae_t5_utils.set_schedule_decoder (:290-375): two groups by substring, one lr -- ParamStore.adamw_step."""
-        return self.store
+        tr = getattr(self, "trainer_ref", None)
+        return self.store.make_optimizer(getattr(tr, "max_steps", None) if tr is not None else None)

@@ -105,11 +105,13 @@ class M3AETransformerSS(_Base):
 
     # ------------------------------------------------------------------------------------------------------
     def _load(self, path):
-        ckpt = torch.load(path, map_location="cpu")
+        # upstream checkpoints are Lightning pickles (callbacks / hyper_parameters hold class globals): the weights-only
+        # unpickler of torch >= 2.6 rejects them, as it would for the reference's own torch.load (m3ae_module.py:105)
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
         sd = adapt_position_encoding(ckpt["state_dict"], after=self.hparams.config["image_size"],
                                      patch_size=self.hparams.config["patch_size"])
         self.load_state_dict(sd, strict=False)
-        if self.store is not None:
+        if getattr(self, "store", None) is not None:   # also reachable from __init__ (load_path), before finalize()
             self.store.sync_shadows()
 
     def weight_units(self):
@@ -255,8 +257,15 @@ class M3AETransformerSS(_Base):
                     for k, v in output.items() if k.endswith("_loss")])
 
     def configure_optimizers(self):
-        """m3ae_utils.py:112-242: the 6-group AdamW + polynomial decay live in ParamStore.adamw_step (fused)."""
-        return self.store
+        """m3ae_module.py:372-373 -> m3ae_utils.set_schedule (:112-242): `([optimizer], [{"scheduler", "interval": "step"}])`.
+        The optimizer is a torch.optim.Optimizer (six param groups) whose step() is the fused AdamW over the flat buffers;
+        the scheduler is a LambdaLR with the reference's polynomial (or cosine) decay with warm-up.  max_steps comes from
+        the attached trainer when there is one (m3ae_utils.py:212-219), else from the config."""
+        max_steps = None
+        tr = getattr(self, "_trainer", None) or getattr(self, "trainer_ref", None)
+        if tr is not None and getattr(tr, "max_steps", None) not in (None, -1):
+            max_steps = tr.max_steps
+        return self.store.make_optimizer(max_steps)
 
 
 def state_dict_spec(config):

@@ -130,4 +130,5 @@ class T5VQA_MMEncoderInput(_Base):
     def configure_optimizers(self):
         """m3ae_t5_utils.set_schedule_decoder (:290-375; `set_schedule` itself is commented out in the reference,
         SURVEY 9 #2): two groups, one lr, poly decay -- fused in ParamStore.adamw_step."""
-        return self.store
+        tr = getattr(self, "trainer_ref", None)
+        return self.store.make_optimizer(getattr(tr, "max_steps", None) if tr is not None else None)

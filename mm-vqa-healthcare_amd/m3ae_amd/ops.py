@@ -20,6 +20,9 @@ grad_ready_hook = None  # callable(param) set by the DDP reducer
 # forward activation GEMMs save act'(pre-activation) for their backward GEMM (A/B knob: M3AE_SAVE_DACT=0 saves the
 # pre-activation and re-evaluates the derivative in the backward epilogue, the first scheme of this repo)
 SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
+# host-side launch policy, set by ddp.FlatGradReducer while collectives run next to backward (per-call flag in the GEMM
+# descriptor: the library itself keeps no state)
+NT_NO_PERSISTENT = False
 PROFILE = None  # when a list: every GEMM / attention launch is bracketed by HIP events on the launch stream
 
 
@@ -107,6 +110,7 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
             setattr(d, name, t.data_ptr())
     d.dact = dact
     d.preact_grad = int(preact_grad)
+    d.launch_flags = 1 if NT_NO_PERSISTENT else 0
     d.force_generic = int(force_generic)
     if a_rowsum is not None:
         assert a_rowsum.dtype == torch.float32 and a_rowsum.numel() >= M and batch == (1, 1)

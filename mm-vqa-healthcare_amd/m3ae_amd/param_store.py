@@ -200,25 +200,36 @@ class ParamStore:
         lr_init, lr_end, power = cfg["learning_rate"], cfg["end_lr"], cfg["decay_power"]
         if step < warm:
             return float(step) / float(max(1, warm))
+        if power == "cosine":  # transformers get_cosine_schedule_with_warmup (m3ae_utils.py:225-230), half a cosine
+            progress = float(step - warm) / float(max(1, max_steps - warm))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
         if step > max_steps:
             return lr_end / lr_init
         pct = 1 - (step - warm) / (max_steps - warm)
         return ((lr_init - lr_end) * pct ** power + lr_end) / lr_init
 
     @torch.no_grad()
-    def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None):
+    def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None, group_lrs=None, betas=(0.9, 0.98), eps=1e-8,
+                   group_wds=None):
         """One AdamW step over the six group segments (m3ae_utils.py:206; transformers-4.6.0 AdamW semantics,
-        betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step."""
+        betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step.
+        `group_lrs` (one learning rate per group, e.g. an Optimizer's param_groups after its scheduler stepped) overrides
+        the built-in schedule."""
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.grad)
             self.exp_avg_sq = torch.zeros_like(self.grad)
-        if lr_factor is None:
-            max_steps = max_steps or self.cfg["max_steps"]
-            lr_factor = self.lr_factor(self.step_count, max_steps)
+        hp = self.hparams_fn(self.cfg)
+        if group_lrs is None:
+            if lr_factor is None:
+                max_steps = max_steps or self.cfg["max_steps"]
+                lr_factor = self.lr_factor(self.step_count, max_steps)
+            group_lrs = [lr * lr_factor for lr, _ in hp]
+        if group_wds is None:
+            group_wds = [wd for _, wd in hp]
         self.step_count += 1
         L = _lib.lib()
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for gi, (lr, wd) in enumerate(self.hparams_fn(self.cfg)):
+        for gi in range(6):
             a, b = self.segments[gi]
             if b <= a:
                 continue
@@ -226,9 +237,94 @@ class ParamStore:
             sh = C.c_void_p(self.shadow.data_ptr() + a * 2) if self.shadow is not None else None
             _lib.check(L.m3ae_adamw(C.c_void_p(self.flat.data_ptr() + a * es), C.c_void_p(self.grad.data_ptr() + a * es),
                                     C.c_void_p(self.exp_avg.data_ptr() + a * es),
-                                    C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, lr * lr_factor, 0.9,
-                                    0.98, 1e-8, wd, self.step_count, grad_scale, s), "m3ae_adamw")
+                                    C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, float(group_lrs[gi]),
+                                    float(betas[0]), float(betas[1]), float(eps), float(group_wds[gi]), self.step_count,
+                                    grad_scale, s), "m3ae_adamw")
         self.sync_shadows(cast=False)
+
+    def make_optimizer(self, max_steps=None):
+        """([optimizer], [{"scheduler", "interval": "step"}]) in the shape m3ae_utils.set_schedule returns (:240-242)."""
+        max_steps = max_steps or self.cfg["max_steps"]
+        opt = FlatAdamW(self)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: self.lr_factor(step, max_steps))
+        return [opt], [{"scheduler": sched, "interval": "step"}]
 
     def group_names(self):
         return [[n for n, _ in g] for g in self.groups[:6]]
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim.Optimizer face of ParamStore's fused AdamW (the object m3ae_utils.set_schedule returns as
+    `optimizer`, m3ae_utils.py:135-206): six param groups -- {base, head x lr_multiplier_head, multi_modal x
+    lr_multiplier_multi_modal} x {weight decay, no decay} -- with the reference's lr / weight_decay / betas / eps per group,
+    so a Lightning-style loop (`optimizer.step(); scheduler.step(); optimizer.zero_grad()`) and LambdaLR schedulers work.
+    `step()` is one fused kernel launch per group over the flat buffers; the learning rates are read from
+    `param_groups[i]["lr"]` (whatever a scheduler wrote there).  `state_dict()` / `load_state_dict()` round-trip the
+    moments (per parameter, torch's layout) and the step count."""
+
+    def __init__(self, store, grad_scale=1.0):
+        self.store = store
+        self.grad_scale = grad_scale
+        groups = []
+        for gi, (lr, wd) in enumerate(store.hparams_fn(store.cfg)):
+            params = [p for _, p in store.groups[gi]]
+            if not params:   # torch rejects empty groups: keep the slot with a placeholder so that indices stay group ids
+                params = [torch.nn.Parameter(torch.zeros(0, device=store.device), requires_grad=False)]
+            groups.append(dict(params=params, lr=lr, weight_decay=wd, m3ae_group=gi))
+        super().__init__(groups, dict(lr=store.cfg["learning_rate"], betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0))
+
+    def _bind_state(self):
+        st = self.store
+        if st.exp_avg is None:
+            st.exp_avg = torch.zeros_like(st.grad)
+            st.exp_avg_sq = torch.zeros_like(st.grad)
+        for gi in range(6):
+            for _, p in st.groups[gi]:
+                o = st.offset[id(p)]
+                self.state[p] = dict(step=torch.tensor(float(st.step_count)),
+                                     exp_avg=st.exp_avg[o:o + p.numel()].view(p.shape),
+                                     exp_avg_sq=st.exp_avg_sq[o:o + p.numel()].view(p.shape))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g = {pg["m3ae_group"]: pg for pg in self.param_groups}
+        self.store.adamw_step(group_lrs=[g[i]["lr"] for i in range(6)], group_wds=[g[i]["weight_decay"] for i in range(6)],
+                              betas=g[0]["betas"], eps=g[0]["eps"], grad_scale=self.grad_scale)
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        self.store.zero_grad()   # gradients are views of the flat buffer: never set to None
+
+    def state_dict(self):
+        self._bind_state()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        st = self.store
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        mine = [p for g in self.param_groups for p in g["params"]]
+        if len(ids) != len(mine):
+            raise ValueError("optimizer state_dict does not match this model's parameter groups")
+        if st.exp_avg is None:
+            st.exp_avg = torch.zeros_like(st.grad)
+            st.exp_avg_sq = torch.zeros_like(st.grad)
+        step = None
+        for i, p in zip(ids, mine):
+            s = state_dict["state"].get(i)
+            if s is None or id(p) not in st.offset or p.numel() == 0:
+                continue
+            o = st.offset[id(p)]
+            st.exp_avg[o:o + p.numel()].view(p.shape).copy_(s["exp_avg"])
+            st.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(s["exp_avg_sq"])
+            step = int(s["step"]) if step is None else step
+        if step is not None:
+            st.step_count = step
+        for pg, sg in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "weight_decay", "betas", "eps", "initial_lr"):
+                if k in sg:
+                    pg[k] = sg[k]
+        self._bind_state()

@@ -25,6 +25,7 @@ the GPU); `data_root=synthetic` (or empty) selects `SyntheticDataModule`, which 
 same collate schema (base_dataset.py:165-228).
 """
 import json
+import math
 import os
 import sys
 import time
@@ -50,11 +51,15 @@ def grad_steps_of(cfg, world):
 def plan(cfg, world, train_samples):
     """Optimizer-step budget exactly as main.py:49-52 + Lightning derive it."""
     gs = grad_steps_of(cfg, world)
-    micro_per_epoch = max(train_samples // (cfg["per_gpu_batchsize"] * world), 1)  # DistributedSampler, drop_last=False~
-    steps_per_epoch = max(micro_per_epoch // gs, 1)
+    # len(train_dataloader): DistributedSampler gives every rank ceil(n / world) samples, the loader keeps the ragged last
+    # batch (drop_last=False) -> ceil; Lightning steps the optimizer on an epoch's last batch even when the accumulation
+    # window is incomplete -> ceil again for the steps of an epoch
+    micro_per_epoch = max(math.ceil(math.ceil(train_samples / world) / cfg["per_gpu_batchsize"]), 1)
+    steps_per_epoch = max(math.ceil(micro_per_epoch / gs), 1)
     ms = cfg["max_steps"]
     if ms is None or ms < 0:
-        max_steps, max_epochs = steps_per_epoch * cfg["max_epoch"], cfg["max_epoch"]
+        # m3ae_utils.py:212-217: len(train_dataloader) * max_epochs // accumulate_grad_batches
+        max_steps, max_epochs = max(micro_per_epoch * cfg["max_epoch"] // gs, 1), cfg["max_epoch"]
     else:
         max_steps, max_epochs = ms, 1000
     return dict(grad_steps=gs, micro_per_epoch=micro_per_epoch, steps_per_epoch=steps_per_epoch, max_steps=max_steps,
@@ -96,7 +101,7 @@ class SyntheticDataModule:
         return b
 
     def train_batches(self, epoch):
-        n = max(self.train_samples // (self.B * self.world), 1)
+        n = max(math.ceil(math.ceil(self.train_samples / self.world) / self.B), 1)   # == plan()'s micro_per_epoch
         for i in range(n):
             yield self.pool[(epoch * n + i) % len(self.pool)]
 
@@ -122,6 +127,13 @@ class Trainer:
         self.store = model.store
         self.reducer = FlatGradReducer(self.store)
         self.plan = plan(cfg, world, dm.train_samples)
+        if cfg["decay_power"] != "cosine" and not isinstance(cfg["decay_power"], (int, float)):
+            raise ValueError(f"decay_power must be a number or 'cosine' (m3ae_utils.py:225), got {cfg['decay_power']!r}")
+        # the reference's ([optimizer], [{"scheduler", "interval": "step"}]) (m3ae_utils.py:240-242), driven as Lightning drives it
+        self.max_steps = self.plan["max_steps"]
+        model.trainer_ref = self
+        opts, scheds = model.configure_optimizers()
+        self.optimizer, self.scheduler = opts[0], scheds[0]["scheduler"]
         self.global_step, self.epoch, self.best = 0, 0, -1.0
         self.log_every = log_every
         exp = cfg["exp_name"]
@@ -137,12 +149,9 @@ class Trainer:
         os.makedirs(self.ckpt_dir, exist_ok=True)
         ck = {"state_dict": state_dict_cpu(self.model), "global_step": self.global_step, "epoch": self.epoch,
               "hyper_parameters": {"config": {k: v for k, v in self.cfg.items()}}, "val/the_metric": metric}
-        if not self.weights_only:
-            st = self.store
-            ck["optimizer_flat"] = {"step_count": st.step_count,
-                                    "exp_avg": None if st.exp_avg is None else st.exp_avg.cpu(),
-                                    "exp_avg_sq": None if st.exp_avg_sq is None else st.exp_avg_sq.cpu(),
-                                    "names": st.group_names()}
+        if not self.weights_only:   # Lightning's keys
+            ck["optimizer_states"] = [self.optimizer.state_dict()]
+            ck["lr_schedulers"] = [self.scheduler.state_dict()]
         path = os.path.join(self.ckpt_dir, name)
         torch.save(ck, path)
         return path
@@ -152,11 +161,20 @@ class Trainer:
         self.model.load_state_dict(ck["state_dict"], strict=False)
         self.store.sync_shadows()
         self.global_step, self.epoch = ck.get("global_step", 0), ck.get("epoch", 0)
-        of = ck.get("optimizer_flat")
-        if of is not None and of["exp_avg"] is not None:
+        of = ck.get("optimizer_flat")   # checkpoints written before the Optimizer face existed
+        if ck.get("optimizer_states"):
+            self.optimizer.load_state_dict(ck["optimizer_states"][0])
+            self.scheduler.load_state_dict(ck["lr_schedulers"][0])
+        elif of is not None and of["exp_avg"] is not None:
             self.store.exp_avg = of["exp_avg"].to(self.device)
             self.store.exp_avg_sq = of["exp_avg_sq"].to(self.device)
-        self.store.step_count = of["step_count"] if of is not None else self.global_step
+            self.store.step_count = of["step_count"]
+        if not ck.get("optimizer_states"):
+            if of is None:
+                self.store.step_count = self.global_step
+            self.scheduler.last_epoch = self.store.step_count   # LambdaLR: lr = base * lambda(last_epoch)
+            for g, base in zip(self.optimizer.param_groups, self.scheduler.base_lrs):
+                g["lr"] = base * self.store.lr_factor(self.store.step_count, self.max_steps)
         return ck
 
     # -- loops ------------------------------------------------------------------------------------------------
@@ -200,20 +218,27 @@ class Trainer:
         t0, seen = time.perf_counter(), 0
         done = self.global_step >= P["max_steps"]
         while not done and self.epoch < P["max_epochs"]:
-            micro = 0
-            for batch in self.dm.train_batches(self.epoch):
-                first, last = micro % gs == 0, micro % gs == gs - 1
+            micro, nbatch = 0, 0   # position inside the accumulation window / batches of this epoch
+            it = iter(self.dm.train_batches(self.epoch))
+            nxt = next(it, None)
+            while nxt is not None:
+                batch, nxt = nxt, next(it, None)
+                # a window ends after grad_steps micro-batches -- or with the epoch (Lightning steps on the last batch)
+                first, last = micro % gs == 0, (micro % gs == gs - 1 or nxt is None)
                 if first:
-                    self.store.zero_grad()
+                    self.optimizer.zero_grad()
                 # exchange gradients only on the window's last micro-batch (Lightning skips the DDP sync otherwise)
                 (self.reducer.attach() if last else self.reducer.detach())
                 loss = self._loss(batch) / gs
                 loss.backward()
-                micro += 1
+                micro = 0 if last else micro + 1
+                nbatch += 1
                 seen += cfg["per_gpu_batchsize"] * self.world
                 if last:
                     self.reducer.finish()
-                    self.store.adamw_step(max_steps=P["max_steps"], grad_scale=self.reducer.grad_scale)
+                    self.optimizer.grad_scale = self.reducer.grad_scale
+                    self.optimizer.step()
+                    self.scheduler.step()
                     self.global_step += 1
                     if self.global_step % self.log_every == 0 or self.global_step == 1:
                         lv = loss.item() * gs
@@ -224,7 +249,7 @@ class Trainer:
                             f"{seen / dt:.1f} pairs/s", self.rank)
                     if self.global_step >= P["max_steps"]:
                         done = True
-                if micro % val_every == 0 or done:
+                if nbatch % val_every == 0 or done:
                     m = self.validate()
                     log(f"val/the_metric {m:.4f} (best {max(self.best, m):.4f})", self.rank)
                     if m > self.best:

@@ -99,10 +99,25 @@ def test_trainer_plan_follows_reference_main():
     assert trainer.grad_steps_of(cfg, 1) == 8 and trainer.grad_steps_of(cfg, 8) == 1
     p = trainer.plan(cfg, 1, 3064)
     assert p["grad_steps"] == 8 and p["max_steps"] == 1000 and p["max_epochs"] == 1000  # named config: max_steps=1000
-    assert p["micro_per_epoch"] == 383 and p["steps_per_epoch"] == 47
+    # len(train_dataloader) is a ceil (drop_last=False) and Lightning steps on an epoch's last batch: ceil(383 / 8) = 48
+    assert p["micro_per_epoch"] == 383 and p["steps_per_epoch"] == 48
     cfg2 = config.parse_cli(argv + ["max_steps=-1"])
     p2 = trainer.plan(cfg2, 2, 3064)
-    assert p2["grad_steps"] == 4 and p2["max_epochs"] == 70 and p2["max_steps"] == 70 * (3064 // 16 // 4)
+    # m3ae_utils.py:212-217: len(train_dataloader) * max_epochs // accumulate_grad_batches, per rank ceil(3064 / 2) = 1532 samples
+    assert p2["grad_steps"] == 4 and p2["max_epochs"] == 70 and p2["micro_per_epoch"] == 192
+    assert p2["max_steps"] == 192 * 70 // 4
+    # VQA-RAD at per-GPU batch 64: 47.9 batches -> 48 (Lightning), not 47
+    cfg3 = config.parse_cli(argv + ["per_gpu_batchsize=64", "max_steps=-1"])
+    assert trainer.plan(cfg3, 1, 3064)["micro_per_epoch"] == 48
+    # schedule: polynomial (default) and cosine (m3ae_utils.py:225-238) with warm-up
+    from m3ae_amd.param_store import ParamStore
+    st = ParamStore.__new__(ParamStore)
+    st.cfg = dict(cfg, warmup_steps=0.1, decay_power="cosine", learning_rate=1e-5, end_lr=0)
+    assert st.lr_factor(0, 1000) == 0.0 and abs(st.lr_factor(50, 1000) - 0.5) < 1e-12
+    assert abs(st.lr_factor(100, 1000) - 1.0) < 1e-12 and abs(st.lr_factor(550, 1000) - 0.5) < 1e-12
+    assert st.lr_factor(1000, 1000) < 1e-12
+    st.cfg["decay_power"] = 1
+    assert abs(st.lr_factor(550, 1000) - 0.5) < 1e-12
     # VQA score (my_metrics.py:66-79): soft target at the arg-max logit
     logits = torch.tensor([[0.1, 2.0, -1.0], [3.0, 0.0, 0.5]])
     targets = torch.tensor([[0.0, 0.6, 1.0], [0.0, 1.0, 0.0]])
@@ -185,3 +200,38 @@ def test_collate_host_adds_mlm_fields(tmp_path):
     sel = hb["text_labels_mlm"] != -100
     assert sel.any() and torch.equal(hb["text_labels_mlm"][sel], hb["text_ids"][sel])
     assert torch.equal(hb["text_ids_mlm"][~sel], hb["text_ids"][~sel])
+
+
+class FakeModelCheckpoint:                  # a class global inside the pickle, as Lightning writes its callbacks
+    best_model_score = 0.5
+
+
+def test_load_path_accepts_a_lightning_shaped_checkpoint(tmp_path):
+    """Upstream checkpoints are Lightning pickles: `callbacks` keyed by a class, `hyper_parameters` with arbitrary objects.
+    torch >= 2.6 defaults torch.load to weights_only=True, which rejects them; M3AETransformerSS._load (the load_path route
+    of m3ae_module.py:103-113) must read them as the reference's torch.load does -- including the positional-embedding
+    resize (clip_model.py:224-251) when the checkpoint was trained at another resolution."""
+    import collections
+    from m3ae_amd.config import tiny_config
+    from m3ae_amd.modules import M3AETransformerSS
+    from m3ae_amd.modules.m3ae_module import state_dict_spec
+
+    cfg_a = tiny_config(image_size=32)          # checkpoint resolution: (32 / 16)^2 + 1 = 5 positions
+    sd = {k: torch.randn(v) * 0.02 for k, v in state_dict_spec(cfg_a).items()}
+
+    ck = {"state_dict": sd, "epoch": 3, "global_step": 77, "pytorch-lightning_version": "1.3.2",
+          "callbacks": {FakeModelCheckpoint: {"best_model_score": torch.tensor(0.5), "best_model_path": "x.ckpt"}},
+          "hyper_parameters": {"config": collections.OrderedDict(cfg_a), "obj": FakeModelCheckpoint()},
+          "optimizer_states": [], "lr_schedulers": []}
+    path = str(tmp_path / "upstream.ckpt")
+    torch.save(ck, path)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)   # what an argument-less torch.load does on torch >= 2.6
+    m = M3AETransformerSS(tiny_config(image_size=64, load_path=path))   # 64 px: 17 positions -> bicubic resize on load
+    got = m.state_dict()
+    pe = "vision_encoder.visual.positional_embedding"
+    assert got[pe].shape[0] == 17 and sd[pe].shape[0] == 5
+    assert torch.equal(got[pe][0], sd[pe][0])                       # the class position is carried over unchanged
+    for k in ("vision_encoder.visual.conv1.weight", "multi_modal_language_layers.1.crossattention.self.key.weight",
+              "language_encoder.embeddings.word_embeddings.weight"):
+        assert torch.equal(got[k], sd[k]), k

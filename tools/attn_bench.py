@@ -43,8 +43,7 @@ for (Lq, Lk, masked) in [(577, 577, False), (32, 577, False), (577, 32, True), (
     o, lse = ops.attn_forward(q, k, v, H, mask)
     do = torch.randn_like(o)
     fl = 4.0 * B * H * Lq * Lk * 64
-    for coop, drop in ((0, None), (1, None), (1, (0.1, 1234))):   # dropout instances exist for the cooperative kernels only
-        _lib.lib().m3ae_set_tuning(2, coop)
+    for coop, drop in ((1, None), (1, (0.1, 1234))):
         tf = time_it(lambda: ops.attn_forward(q, k, v, H, mask, dropout=drop))
         tb = time_it(lambda: ops.attn_backward(q, k, v, o, lse, do, dq, dk, dv, H, mask, dropout=drop))
         print(f"attn coop={coop} drop={0.0 if drop is None else drop[0]} Lq={Lq:4d} Lk={Lk:4d}: fwd {tf*1e3:8.1f} us {fl/tf/1e9:7.1f} TF/s | "
