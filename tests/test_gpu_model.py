@@ -883,7 +883,8 @@ def test_bench_line_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--batch", "64", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+                        "--batch", "64", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600,
+                       cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -900,5 +901,10 @@ def test_bench_line_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert 0 < r["achieved"] < r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     assert d["cpu_baseline"] is None          # switched off above; the default run carries it
+    assert d["secondary"] is None             # likewise (configs[2] line, a child process in the default run)
+    sm = d["step_ms"]
+    assert sm["min"] <= sm["p10"] <= sm["median"] <= sm["p90"] <= sm["max"] and sm["min"] > 0
+    x = d["cross_attention_fwd"]
+    assert x["path"].startswith("m3ae_xattn_fwd") and x["tflop"] == round(17.922 * 64 / 1e3, 3)
     x = d["cross_attention_fwd"]
     assert x["batch"] == 64 and 0 < x["frac"] < 1
