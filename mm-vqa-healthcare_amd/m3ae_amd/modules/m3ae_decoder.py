@@ -94,6 +94,32 @@ class DecoderLayer(nn.Module):
                         residual=x)
         return self._ln(self.layernorm3, x)
 
+    @torch.no_grad()
+    def cross_kv(self, enc):
+        """Keys | values of the multimodal features for mha2 ([B, Le, 2 D]): computed once per generation."""
+        D = self.mha1.embed_dim
+        return ops.linear(enc, self.mha2.in_proj_weight, self.mha2.in_proj_bias)[..., D:]
+
+    @torch.no_grad()
+    def step(self, t_new, enc_kv, cache, pos):
+        """Inference: ONE new position `pos` (t_new [B, 1, D]).  Its self-attention key | value row is appended to `cache`
+        [B, Tmax, 2 D]; the new query attends to rows 0..pos -- the keys the causal mask leaves to the last row of a
+        full-prefix pass -- and to the cached encoder-side keys / values.  Same kernels as forward()."""
+        D, H = self.mha1.embed_dim, self.mha1.num_heads
+        B = t_new.shape[0]
+        xn = self._ln(self.pre_norm, t_new)
+        qkv = ops.linear(xn, self.mha1.in_proj_weight, self.mha1.in_proj_bias)          # [B, 1, 3 D]
+        cache[:, pos].copy_(qkv[:, 0, D:])
+        ctx, _ = ops.attn_forward(qkv[..., :D], cache[:, :pos + 1, :D], cache[:, :pos + 1, D:], H)
+        x = ops.linear(ctx, self.mha1.out_proj.weight, self.mha1.out_proj.bias, residual=t_new)
+        xn = self._ln(self.layernorm1, x)
+        q = ops.linear(xn, self.mha2.in_proj_weight, self.mha2.in_proj_bias)[..., :D]
+        ctx, _ = ops.attn_forward(q, enc_kv[..., :D], enc_kv[..., D:], H)
+        x = ops.linear(ctx, self.mha2.out_proj.weight, self.mha2.out_proj.bias, residual=x)
+        xn = self._ln(self.layernorm2, x)
+        x = ops.mlp(xn, self.ffn[0].weight, self.ffn[0].bias, self.ffn[2].weight, self.ffn[2].bias, ops.ACT_RELU, residual=x)
+        return self._ln(self.layernorm3, x)
+
 
 class PositionalEncoding(nn.Module):
     """m3ae_decoder.py:22-36 (fixed sinusoid table, a persistent buffer)."""
@@ -169,13 +195,33 @@ class Decoder(nn.Module):
         return ops.linear(x, self.final_linear.weight, self.final_linear.bias)
 
     @torch.no_grad()
-    def search_path(self, cross_attn_feats, cls_id=101, sep_id=102, eos_id=None, pad_id=0):
-        """m3ae_decoder.py:141-182: greedy decoding, the whole prefix re-run every step (as the reference does)."""
+    def step_logits(self, last_ids, pos, enc_kv, cache):
+        """Logits of the next token from the NEW token alone (last_ids [B, 1] at position `pos`): the prefix's keys / values
+        come from `cache`, the encoder side from `enc_kv`; equal to forward(prefix)[:, -1] (eval mode)."""
+        B = last_ids.shape[0]
+        pe_rows = self.positional_encoding.pe[0, pos:pos + 1].to(torch.float32).repeat(B, 1).contiguous()
+        t = _DecoderEmbedFn.apply(last_ids.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows)
+        x = self.dec_layers[self.num_layers - 1].step(t.view(B, 1, -1), enc_kv, cache, pos)
+        return ops.linear(x, self.final_linear.weight, self.final_linear.bias)[:, -1]
+
+    @torch.no_grad()
+    def search_path(self, cross_attn_feats, cls_id=101, sep_id=102, eos_id=None, pad_id=0, use_cache=True):
+        """m3ae_decoder.py:141-182: greedy decoding.  The reference re-runs the whole prefix every step; here a step is one
+        decoder row: the prefix's self-attention keys / values are cached, the encoder-side keys / values are projected
+        once (`use_cache=False` keeps the reference's loop; both give the same tokens)."""
         B, dev = cross_attn_feats.shape[0], cross_attn_feats.device
         seq = torch.full((B, 1), cls_id, dtype=torch.long, device=dev)
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
-        for _ in range(self.max_len):
-            nxt = self.forward(seq, None, cross_attn_feats)[:, -1].argmax(dim=-1)
+        layer = self.dec_layers[self.num_layers - 1]
+        if use_cache:
+            D = self.target_embedding.weight.shape[1]
+            enc_kv = layer.cross_kv(cross_attn_feats)
+            cache = torch.empty((B, self.max_len, 2 * D), dtype=torch.float32, device=dev)
+        for step in range(self.max_len):
+            if use_cache:
+                nxt = self.step_logits(seq[:, -1:], step, enc_kv, cache).argmax(dim=-1)
+            else:
+                nxt = self.forward(seq, None, cross_attn_feats)[:, -1].argmax(dim=-1)
             hit = nxt == sep_id
             if eos_id is not None:
                 hit = hit | (nxt == eos_id)

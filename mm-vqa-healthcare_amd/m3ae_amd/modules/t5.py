@@ -199,6 +199,32 @@ class T5Stack(nn.Module):
         ln = self.final_layer_norm
         return ops.dropout(ops.layer_norm(h2.view(B, T, D), ln.weight, None, ln.eps, rms=True), self.dropout_rate, self.training)
 
+    @torch.no_grad()
+    def new_self_cache(self, B, max_len, dtype, device):
+        """Decoder only: per block a [B, max_len, 2 inner] buffer of the prefix's self-attention keys | values
+        (HF keeps them in `past_key_values`; m3ae_t5_mm_encoder_input.py:209-227 decodes through them)."""
+        inner2 = 2 * self.block[0].params().attn.w_o.shape[1]
+        return [torch.empty((B, max_len, inner2), dtype=dtype, device=device) for _ in self.block]
+
+    @torch.no_grad()
+    def step_cached(self, h_new, cross_kv, Ls, self_cache, t):
+        """Decoder only, inference: ONE new position t (h_new [B, 1, D]) through the blocks' own kernels; its key / value row
+        is appended to `self_cache`, the attention of the new query runs over the cached rows 0..t (exactly the keys the
+        causal mask leaves to the last row of a full-prefix pass), the encoder side comes from `cross_kv`."""
+        B, _, D = h_new.shape
+        pd = self.dropout_rate if self.training else 0.0
+        h = ops.dropout(h_new, self.dropout_rate, self.training)
+        sa = self.block[0].layer[0].SelfAttention
+        bias = sa.position_bias(t + 1, t + 1).detach()[:, t:t + 1, :].contiguous()   # the last query's row [H, 1, t + 1]
+        h2 = h.contiguous().view(B, D)
+        for blk, kv, cache in zip(self.block, cross_kv, self_cache):
+            P = blk.params()
+            a = ops.t5_self_attn_step(h2, B, P.attn, bias, cache, t, pd)
+            c, _ = ops._t5_attn_fwd(a, B, 1, None, Ls, P.cross, None, False, pd, kv=kv)
+            h2, _ = ops._t5_ff_fwd(c, P.ffn, pd)
+        ln = self.final_layer_norm
+        return ops.dropout(ops.layer_norm(h2.view(B, 1, D), ln.weight, None, ln.eps, rms=True), self.dropout_rate, self.training)
+
     def weight_units(self):
         u = []
         for b in self.block:
@@ -234,18 +260,26 @@ class T5ForConditionalGeneration(nn.Module):
         w = self.shared.weight
         table = ops.compute_weight(w) if dtype == torch.bfloat16 else w
         B, T = ids.shape
-        return ops.EmbedRowsFn.apply(ids.reshape(-1), w, table).view(B, T, -1)
+        return ops.EmbedRowsFn.apply(ids.reshape(-1).contiguous(), w, table).view(B, T, -1)   # (a [B, 1] slice reshapes to a STRIDED view)
 
     @torch.no_grad()
     def next_token_logits(self, enc, prefix, cross_kv=None):
         """Decoder over the whole prefix (T <= 12 here: the self-attention keys are recomputed, the 512-token encoder
-        side comes from `cross_kv` when given) -> logits of the last position, fp32."""
+        side comes from `cross_kv` when given) -> logits of the last position, fp32.  (`generate` uses
+        `next_token_logits_cached`; this full-prefix form is what it is tested against.)"""
         if cross_kv is not None:
             dec = self.decoder.forward_cached(self.embed(prefix, enc.dtype), cross_kv, enc.shape[1])
         else:
             dec = self.decoder(self.embed(prefix, enc.dtype), enc)
         last = dec[:, -1].contiguous()
         return ops.linear(last, self.shared.weight, None, alpha=self.config.d_model ** -0.5).float()
+
+    @torch.no_grad()
+    def next_token_logits_cached(self, enc, last_ids, cross_kv, self_cache, t):
+        """The same logits from the NEW token alone (last_ids [B, 1] at position t): the prefix's self-attention keys /
+        values come from `self_cache` (HF `past_key_values`), so a step costs one decoder row instead of t + 1."""
+        dec = self.decoder.step_cached(self.embed(last_ids, enc.dtype), cross_kv, enc.shape[1], self_cache, t)
+        return ops.linear(dec[:, -1].contiguous(), self.shared.weight, None, alpha=self.config.d_model ** -0.5).float()
 
     @torch.no_grad()
     def generate(self, enc, num_beams=4, max_length=12, eos_token_id=1, pad_token_id=0, length_penalty=1.0,
@@ -263,6 +297,8 @@ class T5ForConditionalGeneration(nn.Module):
         Ls = enc.shape[1]
         cross_kv = [kv.view(B, Ls, -1).repeat_interleave(nb, dim=0).reshape(B * nb * Ls, -1) for kv in self.decoder.cross_kv(enc)]
         ids = torch.full((B * nb, 1), self.config.decoder_start_token_id, dtype=torch.long, device=dev)
+        # the beams' own keys / values: one decoder row per step; re-ordered with the beams (HF `_reorder_cache`)
+        self_cache = self.decoder.new_self_cache(B * nb, max_length, enc.dtype, dev)
         beam_scores = torch.zeros(B, nb, device=dev)
         beam_scores[:, 1:] = -1e9
         beam_scores = beam_scores.view(-1)
@@ -270,7 +306,7 @@ class T5ForConditionalGeneration(nn.Module):
         done = [False] * B
         cur_len = 1
         while cur_len < max_length:
-            logp = torch.log_softmax(self.next_token_logits(enc_r, ids, cross_kv), dim=-1)
+            logp = torch.log_softmax(self.next_token_logits_cached(enc_r, ids[:, -1:], cross_kv, self_cache, cur_len - 1), dim=-1)
             V = logp.shape[-1]
             top_s, top_i = torch.topk((logp + beam_scores[:, None]).view(B, nb * V), 2 * nb, dim=1)
             top_s, top_i = top_s.cpu(), top_i.cpu()
@@ -299,7 +335,9 @@ class T5ForConditionalGeneration(nn.Module):
                         break
                 done[b] = done[b] or len(hyps[b]) >= nb
             beam_scores = nxt_scores.view(-1).to(dev)
-            ids = torch.cat([ids[nxt_index.view(-1).to(dev)], nxt_tokens.view(-1, 1).to(dev)], dim=1)
+            order = nxt_index.view(-1).to(dev)
+            ids = torch.cat([ids[order], nxt_tokens.view(-1, 1).to(dev)], dim=1)
+            self_cache = [ops.gather_rows(c.view(B * nb, -1), order).view_as(c) for c in self_cache]
             cur_len += 1
             if all(done):
                 break

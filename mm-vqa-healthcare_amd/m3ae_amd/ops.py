@@ -727,7 +727,9 @@ class BertCrossLayerFn(torch.autograd.Function):
         other2 = other.contiguous().view(B * Lo, other.shape[2])
         pd = getattr(P, "pdrop", 0.0)
         a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask_self, P.attn, pd)
-        c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross, pd)
+        # forward-only calls (validation, generation, the frozen encoder under the T5 / decoder heads): the fused
+        # cross-attention sub-block (csrc/xattn.hip); training keeps the composition, whose backward reads K / V
+        c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross, pd, fused_cross=getattr(P, "fused_cross", False))
         y, s3 = _ffn_sub_fwd(c, P.ffn, pd)
         ctx.saved = (s1, s2, s3)
         ctx.P, ctx.dims, ctx.n_anchor = P, (B, L, Lo, D), len(anchors)
@@ -859,6 +861,24 @@ def _t5_attn_fwd(h2, B, L, src2, Ls, P, bias, causal, pdrop=0.0, kv=None):
     return y, (h2, rstd, n, proj, o, lse, src2, da, dh)
 
 
+def t5_self_attn_step(h2, B, P, bias_row, cache, t, pdrop=0.0):
+    """Generation: the T5 self-attention sub-layer for ONE new position t of every sequence.  h2 [B, D]; `cache` [B, Tmax,
+    2 inner] holds the keys | values of positions < t and receives row t; bias_row [H, 1, t + 1] is the relative-position
+    bias of the new query.  Same kernels, same order as _t5_attn_fwd on the whole prefix (whose last row this equals)."""
+    da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
+    dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
+    n, _, _ = ln_fwd_raw(h2, P.ln, rms=True)
+    D = n.shape[1]
+    inner = P.w_o.shape[1]
+    qkv, _ = mm_nt(n, D, B, compute_weight(P.w_qkv))
+    cache[:, t].copy_(qkv[:, inner:])
+    q = qkv[:, :inner].unsqueeze(1)                        # [B, 1, inner], batch stride 3 inner
+    o, _ = attn_forward(q, cache[:, :t + 1, :inner], cache[:, :t + 1, inner:], P.heads, None, bias_row, scale=1.0,
+                        causal=False, dropout=da)
+    y, _ = mm_nt(o.view(B, inner), inner, B, compute_weight(P.w_o), residual=h2, dropout=dh)
+    return y
+
+
 def _t5_attn_bwd(dy, saved, B, L, Ls, P, bias, causal, dbias, need_dh=True, need_dsrc=True):
     h2, rstd, n, proj, o, lse, src2, da, dh_drop = saved
     need_dh = need_dh or P.ln.weight.requires_grad  # the RMSNorm scale gradient comes out of the same kernel
@@ -980,6 +1000,7 @@ class EmbedRowsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, weight, table):
+        ids = ids.contiguous()   # the kernel walks ids linearly: a strided view (e.g. prefix[:, -1:]) would read its neighbours
         out = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
         check(_lib.lib().m3ae_gather_rows(_p(table), _p(ids), _p(out), ids.numel(), table.shape[1], _dt(table),
                                           _stream()), "m3ae_gather_rows")
@@ -1205,6 +1226,7 @@ def vocab_linear(x, weight, bias):
 class GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, idx):
+        idx = idx.contiguous()
         s2 = src.contiguous().view(-1, src.shape[-1])
         out = torch.empty((idx.numel(), s2.shape[1]), dtype=src.dtype, device=src.device)
         check(_lib.lib().m3ae_gather_rows(_p(s2), _p(idx), _p(out), idx.numel(), s2.shape[1], _dt(s2), _stream()),

@@ -403,8 +403,19 @@ def test_tiny_decoder_generative_head_against_reference_fixture(mode):
             torch.from_numpy(g["cls"]).cuda())
         np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-3, atol=5e-5)
         m.decoder.max_len = 16
-        greedy = m.decoder.search_path(torch.from_numpy(g["cls"]).cuda())
+        feats = torch.from_numpy(g["cls"]).cuda()
+        greedy = m.decoder.search_path(feats)                       # one decoder row per step (key / value cache)
         np.testing.assert_array_equal(greedy.cpu().numpy(), g["greedy"])
+        np.testing.assert_array_equal(m.decoder.search_path(feats, use_cache=False).cpu().numpy(), g["greedy"])
+        # the cached step reproduces the full-prefix logits at every position (m3ae_decoder.py:141-182 re-runs the prefix)
+        toks = torch.from_numpy(g["tokens"][:, :5]).cuda()
+        layer = m.decoder.dec_layers[m.decoder.num_layers - 1]
+        enc_kv = layer.cross_kv(feats)
+        cache = torch.empty((toks.shape[0], 16, 2 * 768), dtype=torch.float32, device="cuda")
+        for t in range(toks.shape[1]):
+            step = m.decoder.step_logits(toks[:, t:t + 1], t, enc_kv, cache)
+            full = m.decoder(toks[:, :t + 1], None, feats)[:, -1]
+            np.testing.assert_allclose(step.cpu().numpy(), full.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_trainer_shim_decoder_head_entry_point(tmp_path):
@@ -488,6 +499,13 @@ def test_t5_generate_matches_oracle_and_third_party(len_offset):
     kv = m.decoder.cross_kv(enc)
     assert len(kv) == 2 and kv[0].shape == (enc.shape[0] * enc.shape[1], 2 * 8 * 64)
     assert torch.equal(m.next_token_logits(enc, prefix), m.next_token_logits(enc, prefix, kv))
+    # the self-attention key / value cache (HF past_key_values; m3ae_t5_mm_encoder_input.py:209-227): feeding the prefix one
+    # token at a time gives, at every position, the logits of the full-prefix pass -- same kernels, same reduction order
+    cache = m.decoder.new_self_cache(enc.shape[0], 8, enc.dtype, enc.device)
+    for t in range(prefix.shape[1]):
+        step = m.next_token_logits_cached(enc, prefix[:, t:t + 1], kv, cache, t)
+        full = m.next_token_logits(enc, prefix[:, :t + 1], kv)
+        assert torch.equal(step, full), (t, float((step - full).abs().max()))
     for eos in g["eos_ids"].tolist():
         mine = m.generate(enc, num_beams=4, max_length=8, eos_token_id=eos, len_offset=len_offset)
         with torch.no_grad():
