@@ -203,6 +203,72 @@ class ArrowVQADataset:
         }
 
 
+class ArrowCaptionDataset:
+    """BaseDataset + ROCODataset / MedicatDataset (pretraining_roco_dataset.py:1-21, pretraining_medicat_dataset.py:1-21):
+    `{data_dir}/{name}_{split}.arrow` written by prepro/make_arrow.py:40-63 (columns image, caption [list of str], image_id,
+    split), one sample per (image row, caption index) (base_dataset.py:72-81), and `get_suite` (:141-163): the image, its
+    caption, and `draw_false_image` negatives drawn as `random.randint(0, len - 1)` over THIS table's samples
+    (`get_false_image`, :107-111) -- Python's `random` stream, as the reference consumes it, so a seeded run reproduces the
+    reference's draws.  A sample that fails to decode is replaced by a random one (:158-160)."""
+
+    def __init__(self, data_dir, name, split, image_size, max_text_len, tokenizer, draw_false_image=0):
+        import pyarrow as pa
+        assert split in ("train", "val", "test")
+        self.names = [f"{name}_{split}"]
+        path = os.path.join(data_dir, f"{self.names[0]}.arrow")
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"no arrow table {path!r}")
+        self.table = pa.ipc.RecordBatchFileReader(pa.memory_map(path, "r")).read_all()
+        self.image_size, self.max_text_len, self.tokenizer = image_size, max_text_len, tokenizer
+        self.draw_false_image = draw_false_image
+        self.all_texts = self.table["caption"].to_pylist()
+        assert isinstance(self.all_texts[0][0], str)
+        self.index_mapper = [(i, j) for i, texts in enumerate(self.all_texts) for j in range(len(texts))]
+
+    def __len__(self):
+        return len(self.index_mapper)
+
+    def image_u8(self, row):
+        from PIL import Image
+        return clip_resize_crop(Image.open(io.BytesIO(self.table["image"][row].as_py())), self.image_size)
+
+    def get_suite(self, index):
+        while True:
+            try:
+                row, ci = self.index_mapper[index]
+                text = self.all_texts[row][ci]
+                enc = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_text_len)
+                ret = {"image_u8": self.image_u8(row), "text": text, "input_ids": list(enc["input_ids"]),
+                       "attention_mask": list(enc["attention_mask"]), "img_index": row, "cap_index": ci,
+                       "raw_index": index, "replica": ci > 0}
+                for rep in range(self.draw_false_image):
+                    frow, _ = self.index_mapper[random.randint(0, len(self.index_mapper) - 1)]
+                    ret[f"false_image_u8_{rep}"] = self.image_u8(frow)
+                return ret
+            except Exception as e:  # noqa: BLE001  (base_dataset.py:158-160)
+                print(f"Error while read file idx {index} in {self.names[0]} -> {e}")
+                index = random.randint(0, len(self.index_mapper) - 1)
+
+    __getitem__ = get_suite
+
+
+class ConcatDataset:
+    """torch.utils.data.ConcatDataset as MTDataModule uses it (multitask_datamodule.py:36-40): datasets back to back."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.ends = np.cumsum([len(p) for p in self.parts]).tolist()
+
+    def __len__(self):
+        return self.ends[-1] if self.ends else 0
+
+    def __getitem__(self, index):
+        for p, end in zip(self.parts, self.ends):
+            if index < end:
+                return p[index - (end - len(p))]
+        raise IndexError(index)
+
+
 def collate_host(samples, pin=True, mlm_collator=None):
     """base_dataset.py:165-228: images stacked as uint8 NHWC, ids / masks as int64 tensors; with `mlm_collator` also
     `text_ids_mlm` / `text_labels_mlm` (:202-209; the reference always computes them, the fine-tuning step never reads
@@ -219,14 +285,18 @@ def collate_host(samples, pin=True, mlm_collator=None):
     if mlm_collator is not None:
         m = mlm_collator([{"input_ids": s["input_ids"]} for s in samples])
         extra = {"text_ids_mlm": m["input_ids"], "text_labels_mlm": m["labels"]}
+    for k in sorted(samples[0]):   # the negatives of the image-text matching objective (base_dataset.py:107-111, :173-195)
+        if k.startswith("false_image_u8_"):
+            extra[k] = torch.from_numpy(np.stack([s[k] for s in samples]))
     if pin and torch.cuda.is_available():
         img, ids, mask = img.pin_memory(), ids.pin_memory(), mask.pin_memory()
         extra = {k: v.pin_memory() for k, v in extra.items()}
-    return {"image_u8": img, "text_ids": ids, "text_masks": mask, **extra,
-            "text": [s["text"] for s in samples],
-            "vqa_answer": [s["vqa_answer"] for s in samples], "vqa_labels": [s["vqa_labels"] for s in samples],
-            "vqa_scores": [s["vqa_scores"] for s in samples], "answer_types": [s["answer_types"] for s in samples],
-            "qid": [s["qid"] for s in samples]}
+    out = {"image_u8": img, "text_ids": ids, "text_masks": mask, **extra, "text": [s["text"] for s in samples]}
+    for k in ("vqa_answer", "vqa_labels", "vqa_scores", "answer_types", "qid", "img_index", "cap_index", "raw_index",
+              "replica"):
+        if k in samples[0]:
+            out[k] = [s[k] for s in samples]
+    return out
 
 
 def to_device_batch(hb, device, copy_stream=None):
@@ -239,9 +309,11 @@ def to_device_batch(hb, device, copy_stream=None):
         mask = hb["text_masks"].to(device, non_blocking=True)
         ev = torch.cuda.Event()
         mlm = {k: hb[k].to(device, non_blocking=True) for k in ("text_ids_mlm", "text_labels_mlm") if k in hb}
+        fal = {"_" + k: hb[k].to(device, non_blocking=True) for k in hb if k.startswith("false_image_u8_")}
         ev.record(cs)
-    out = {k: v for k, v in hb.items() if k not in ("image_u8", "text_ids", "text_masks", "text_ids_mlm", "text_labels_mlm")}
-    out.update(_u8=u8, text_ids=ids, text_masks=mask, text_labels=None, _ready=ev, **mlm)
+    out = {k: v for k, v in hb.items() if k not in ("image_u8", "text_ids", "text_masks", "text_ids_mlm", "text_labels_mlm")
+           and not k.startswith("false_image_u8_")}
+    out.update(_u8=u8, text_ids=ids, text_masks=mask, text_labels=None, _ready=ev, **mlm, **fal)
     return out
 
 
@@ -250,6 +322,10 @@ def finish_batch(db):
     torch.cuda.current_stream().wait_event(db.pop("_ready"))
     u8 = db.pop("_u8")
     db["image"] = [normalize_on_device(u8)]
+    for k in [k for k in db if k.startswith("_false_image_u8_")]:
+        f8 = db.pop(k)
+        f8.record_stream(torch.cuda.current_stream())
+        db["false_image_" + k[len("_false_image_u8_"):]] = [normalize_on_device(f8)]
     db["text_labels"] = torch.full_like(db["text_ids"], -100)
     cur = torch.cuda.current_stream()
     u8.record_stream(cur)
@@ -271,7 +347,13 @@ class ArrowDataModule:
         self.B = cfg["per_gpu_batchsize"]
         self.tokenizer = tokenizer or load_tokenizer(cfg)
         root = cfg["data_root"]
-        mk = lambda split: ArrowVQADataset(root, split, cfg["image_size"], cfg["max_text_len"], self.tokenizer)
+        names = list(cfg.get("datasets") or ["vqa_vqa_rad"])
+        if any(n in ("roco", "medicat") for n in names):   # the pre-training caption tables (config.py:22,31: draw_false_image = 1)
+            mk = lambda split: ConcatDataset([ArrowCaptionDataset(root, n, split, cfg["image_size"], cfg["max_text_len"],
+                                                                  self.tokenizer, cfg.get("draw_false_image", 0))
+                                              for n in names])
+        else:
+            mk = lambda split: ArrowVQADataset(root, split, cfg["image_size"], cfg["max_text_len"], self.tokenizer)
         self.train_set = mk("train")
         self.val_set = self._try(mk, "val") or self.train_set
         self.test_set = self._try(mk, "test") or self.val_set

