@@ -27,7 +27,7 @@
 namespace {
 
 enum { FORM_K = 0, FORM_T = 1 };
-enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3 };
+enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3, XE_DENSE_LN = 4 };
 
 struct XgArgs {
     const bf16_t* A; int64_t lda, a_sb;    // FORM_K: [M][K] (lda = row stride); FORM_T: [K][M] (lda = stride of a k row)
@@ -46,6 +46,8 @@ struct XgArgs {
     int n_valid;                           // XE_SOFTMAXROW: columns >= n_valid are masked out (P = 0)
     DropState drop; int has_drop;
     int H, Lq, drop_ld;                    // dropout index convention of m3ae_attn_desc: ((b*H + h)*Lq + q) * ld + k
+    const float* ln_g; const float* ln_b; float ln_eps;   // XE_DENSE_LN: LayerNorm over the tile's whole rows (BN == N)
+    float* mean_out; float* rstd_out;      // XE_DENSE_LN: [batch * M + m] statistics (nullptr: not kept)
     int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
 };
 
@@ -142,12 +144,16 @@ template <int WN, class RowPtr> DEVINL void slab_store_bf16(const char* slab, in
 // barrier of its phase c - 1; for the late group that barrier is the loaders' second barrier of phase c - 1.
 // Lane layout of the accumulators (D'[n][m] orientation, as gemm_nt_pp_kernel): acc[i][j][r] =
 // C[m = .. + 16 i + (lane & 15)][n = .. + 16 j + 4 (lane >> 4) + r].
-template <int BM, int BN, int WAVES_M, int NSLOT, int AFORM, int BFORM, int EPI>
-__global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
+//   NLOAD == 0 (the 128 x 640 whole-row score tile: 160 accumulators per lane leave no room for a third wave per SIMD): the 8
+//   compute waves stage their own operands in gemm_nt_pp_kernel's two-phase schedule (B part of chunk c + NSLOT - 1 requested
+//   in phase 2c, A part in phase 2c + 1, chunk consumed in two halves of the row blocks).
+template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI>
+__global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(XgArgs a) {
     constexpr int WAVES_N = 8 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
-    constexpr int NLOAD = 4, GA = BM / 16 / NLOAD, GB = BN / 16 / NLOAD, G = GA + GB, DEPTH = NSLOT - 1;
+    constexpr int NST = NLOAD ? NLOAD : 8;   // waves that issue the LDS-DMA pieces
+    constexpr int GA = BM / 16 / NST, GB = BN / 16 / NST, G = GA + GB, DEPTH = NSLOT - 1;
     constexpr int A_BYTES = BM * 64, SLOT = (BM + BN) * 64;
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && WM % 16 == 0 && WN % 16 == 0 && DEPTH >= 2 && DEPTH <= 3, "tile shape");
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && WM % 16 == 0 && WN % 16 == 0 && DEPTH >= 2 && DEPTH <= 3 && (NLOAD == 0 || NLOAD == 4), "tile shape");
     static_assert((AFORM == FORM_K || BM % 128 == 0) && (BFORM == FORM_K || BN % 128 == 0), "T-form operands come in 128-column panels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -161,29 +167,33 @@ __global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
     const int nc = (a.K + 31) >> 5;
     XG_STAMP(0);
 
-    if (wave >= 8) {
+    const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
+    const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
+    const int lw = NLOAD ? wave - 8 : wave;   // index among the staging waves
+    auto stage_b = [&](int c, char* slot) {
+        if constexpr (BFORM == FORM_K) nt_stage<32, GB, NST>(B, a.ldb, n0, a.N, (int64_t)c * 32, slot + A_BYTES, lw, lane);
+        else {
+#pragma unroll
+            for (int p = 0; p < BN / 128; ++p)
+#pragma unroll
+                for (int h = 0; h < 8 / NST; ++h)
+                    t_stage128(B, a.ldb, c * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane);
+        }
+    };
+    auto stage_a = [&](int c, char* slot) {
+        if constexpr (AFORM == FORM_K) nt_stage<32, GA, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
+        else {
+#pragma unroll
+            for (int p = 0; p < BM / 128; ++p)
+#pragma unroll
+                for (int h = 0; h < 8 / NST; ++h)
+                    t_stage128(A, a.lda, c * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane);
+        }
+    };
+    auto stage = [&](int c, char* slot) { stage_b(c, slot); stage_a(c, slot); };
+
+    if (NLOAD > 0 && wave >= 8) {
         // ------------------------------------------------------------------------------------------------ loader waves
-        const int lw = wave - 8;
-        const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
-        const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
-        auto stage = [&](int c, char* slot) {
-            if constexpr (BFORM == FORM_K) nt_stage<32, GB, NLOAD>(B, a.ldb, n0, a.N, (int64_t)c * 32, slot + A_BYTES, lw, lane);
-            else {
-#pragma unroll
-                for (int p = 0; p < BN / 128; ++p)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        t_stage128(B, a.ldb, c * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + 4 * h, lane);
-            }
-            if constexpr (AFORM == FORM_K) nt_stage<32, GA, NLOAD>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
-            else {
-#pragma unroll
-                for (int p = 0; p < BM / 128; ++p)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        t_stage128(A, a.lda, c * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + 4 * h, lane);
-            }
-        };
 #pragma unroll
         for (int c = 0; c < DEPTH; ++c)
             if (c < nc) stage(c, smem + c * SLOT);
@@ -239,6 +249,12 @@ __global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (NLOAD == 0) {
+#pragma unroll
+        for (int c = 0; c < DEPTH; ++c)
+            if (c < nc) stage(c, smem + c * SLOT);
+        wait_vm_chunks<G>((nc < DEPTH ? nc : DEPTH) - 1);
+    }
     PP_FENCE();
     __builtin_amdgcn_s_barrier();   // chunk 0 is in LDS
     PP_FENCE();
@@ -246,6 +262,65 @@ __global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
     XG_STAMP(1);
 
     int cur = 0;
+    if constexpr (NLOAD == 0) {
+        constexpr int HI = MI / 2;
+        static_assert(MI % 2 == 0, "two phases per chunk");
+        int nxt = DEPTH;
+        for (int c = 0; c < nc; ++c) {
+            const char* At = smem + cur * SLOT;
+            char* nx = smem + nxt * SLOT;
+            const bool more = c + DEPTH < nc;
+            s16x8 bfr[NJ], af[HI];
+            // ---------------- phase 2c: first half of the row blocks; B part of chunk c + DEPTH (slot of chunk c - 1: last read in phase 2c - 2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = frag_b(At, j);
+#pragma unroll
+            for (int i = 0; i < HI; ++i) af[i] = frag_a(At, i);
+            if (more) stage_b(c + DEPTH, nx);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < HI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            // ---------------- phase 2c + 1: second half; A part of chunk c + DEPTH (last read in phase 2c - 1); chunk c + 1 landed
+#pragma unroll
+            for (int i = 0; i < HI; ++i) af[i] = frag_a(At, HI + i);
+            if (more) stage_a(c + DEPTH, nx);
+            {
+                const int rem = nc - 1 - c;
+                wait_vm_chunks<G>(rem >= 1 ? (rem - 1 < DEPTH - 1 ? rem - 1 : DEPTH - 1) : 0);
+            }
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < HI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[HI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[HI + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();
+            PP_FENCE();
+            cur = cur + 1 == NSLOT ? 0 : cur + 1;
+            nxt = nxt + 1 == NSLOT ? 0 : nxt + 1;
+        }
+    } else
     for (int c = 0; c < nc; ++c) {
         const char* At = smem + cur * SLOT;
         s16x8 bfr[NJ], af[MI];
@@ -370,6 +445,123 @@ __global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
                         (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (EPI == XE_DENSE_LN) {
+        // BertSelfOutput whole (bert_model.py:360-364): LayerNorm(dropout(dense) + residual) with the tile covering whole
+        // rows (WAVES_M == 1, BN == N): no pre-LayerNorm tensor goes to memory and comes back (the separate LayerNorm pass read
+        // and wrote 227 MB each at B = 256).  The residual tile is DMA-staged into the (free) ring as [BM][N] bf16, its 16-B
+        // chunks XOR-swizzled by the row so that the accumulator-layout reads (16 rows x 8 B per instruction) are conflict
+        // free; statistics in two passes (mean, centred variance: fp32, as norm.hip) through an LDS exchange between the waves.
+        static_assert(WAVES_M == 1, "whole rows per workgroup");
+        constexpr int XRES_BYTES = BM * BN * 2, NPIECE = XRES_BYTES / 1024, CPRW = BN / 8;   // chunks per row
+        static_assert(NPIECE % 8 == 0 && XRES_BYTES + 8 * SLAB_STRIDE + 4 * 8 * BM <= NSLOT * SLOT, "epilogue LDS budget");
+        char* xres = smem;
+        char* slab2 = smem + XRES_BYTES + wave * SLAB_STRIDE;
+        float* red2 = (float*)(smem + XRES_BYTES + 8 * SLAB_STRIDE);   // [8 waves][BM]
+        const int64_t grow0 = (int64_t)bi * a.M;
+        if (a.residual) {
+#pragma unroll
+            for (int q = 0; q < NPIECE / 8; ++q) {
+                const int piece = q * 8 + wave;
+                const int byte = piece * 1024 + lane * 16;
+                const int row = byte / (BN * 2), ch = (byte - row * (BN * 2)) >> 4;
+                int m = m0 + row;
+                m = m < a.M ? m : a.M - 1;
+                glds16(a.residual + (grow0 + m) * a.ldc + ((ch ^ (row & 15)) << 3), xres + piece * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float rsum[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rl_ = i * 16 + (lane & 15);
+            const int64_t gm = grow0 + mw + 16 * i;
+            float s_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nw + 16 * j;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (a.bias) {
+                    const f32x4 b4 = *(const f32x4*)(a.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b4[r];
+                }
+                if (a.has_drop) drop_apply4(a.drop, (uint64_t)(gm * a.N + n), v);
+                if (a.residual) {
+                    const int ch = n >> 3;
+                    const u32x2 rr = *(const u32x2*)(xres + rl_ * (BN * 2) + ((ch ^ (rl_ & 15)) << 4) + (n & 7) * 2);
+                    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; s_ += v[r]; }
+            }
+            rsum[i] = quad16_sum(s_);
+            if (lane < 16) red2[wc * BM + rl_] = rsum[i];
+        }
+        __syncthreads();
+        float mean[MI], rstd[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rl_ = i * 16 + (lane & 15);
+            float t_ = red2[rl_];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t_ += red2[w * BM + rl_];
+            mean[i] = t_ * (1.0f / (float)BN);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rl_ = i * 16 + (lane & 15);
+            float q_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float dlt = acc[i][j][r] - mean[i]; q_ = fmaf(dlt, dlt, q_); }
+            q_ = quad16_sum(q_);
+            if (lane < 16) red2[wc * BM + rl_] = q_;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rl_ = i * 16 + (lane & 15);
+            float t_ = red2[rl_];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t_ += red2[w * BM + rl_];
+            rstd[i] = rsqrtf(t_ * (1.0f / (float)BN) + a.ln_eps);
+            const int m = mw + 16 * i;
+            if (wc == 0 && lane < 16 && m < a.M) {
+                if (a.mean_out) a.mean_out[grow0 + m] = mean[i];
+                if (a.rstd_out) a.rstd_out[grow0 + m] = rstd[i];
+            }
+        }
+#pragma unroll
+        for (int out = 0; out < 2; ++out) {       // out 0: LayerNorm output; out 1: the pre-LayerNorm sum (kept for a backward)
+            if (out == 1 && a.C2 == nullptr) break;
+            bf16_t* dst = out == 0 ? a.C : a.C2;
+#pragma unroll
+            for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * ps + ii;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int n = nw + 16 * j;
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (out == 0) {
+                            const f32x4 g4 = *(const f32x4*)(a.ln_g + n), b4 = *(const f32x4*)(a.ln_b + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaf((v[r] - mean[i]) * rstd[i], g4[r], b4[r]);
+                        }
+                        slab_put_bf16<WN>(slab2, lane, ii, j, v);
+                    }
+                }
+                slab_store_bf16<WN>(slab2, lane, ncols_ok, [&](int row) -> bf16_t* {
+                    const int m = mw0 + 32 * ps + row;
+                    return m < a.M ? dst + (grow0 + m) * a.ldc + nw0 : nullptr;
+                });
+            }
         }
     } else if constexpr (EPI == XE_SOFTMAX32) {
         // image queries: column n = h * 32 + j; one softmax per (row, head) = one pair of 16-column blocks of this wave
@@ -556,12 +748,12 @@ __global__ __launch_bounds__(768, 3) void xg_kernel(XgArgs a) {
 #ifdef M3AE_XG_TRACE
 int g_trace_next = 0;
 #endif
-template <int BM, int BN, int WAVES_M, int NSLOT, int AFORM, int BFORM, int EPI>
+template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI>
 int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
     constexpr int lds = NSLOT * (BM + BN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&xg_kernel<BM, BN, WAVES_M, NSLOT, AFORM, BFORM, EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -571,7 +763,7 @@ int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
     a.trace_slot = g_trace_next++ & 7;
 #endif
     const unsigned grid = (unsigned)(nbatch * a.tiles_m * a.tiles_n);
-    hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, AFORM, BFORM, EPI>), dim3(grid), dim3(768), lds, s, a);
+    hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI>), dim3(grid), dim3(NLOAD ? 768 : 512), lds, s, a);
     return hip_launch_status();
 }
 
@@ -626,7 +818,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
     const int Lq = (int)d.Lq, Lk = (int)d.Lk;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool drop = d.dropout_p > 0.f;
-    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.s || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
+    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
 
     m3ae_gemm_desc g{};
     g.batch1 = g.batch2 = 1;
@@ -648,7 +840,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.M = B * T; a.N = D; a.K = dh;
             a.C = (bf16_t*)d.prime; a.ldc = (int64_t)H * D; a.c_sb = D;
             a.alpha = scale;
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
         }
         {   // P = softmax(Q' y^T + mask) per sample, whole rows per tile
             XgArgs a{};
@@ -663,7 +855,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.n_valid = I;
             a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
             a.H = H; a.Lq = T; a.drop_ld = (int)drop_ld(I);
-            XCHK((launch_xg<64, 640, 1, 3, FORM_K, FORM_K, XE_SOFTMAXROW>(a, B, s)));
+            XCHK((launch_xg<128, 640, 2, 3, 0, FORM_K, FORM_K, XE_SOFTMAXROW>(a, B, s)));
         }
         {   // Z = drop(P) y
             XgArgs a{};
@@ -672,7 +864,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.M = R; a.N = D; a.K = I;
             a.C = (bf16_t*)d.zctx; a.ldc = D; a.c_sb = (int64_t)R * D;
             a.alpha = 1.0f;
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_T, XE_STORE>(a, B, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_STORE>(a, B, s)));
         }
         {   // ctx[b*T + t, h dh + d] = Z[b, t*H + h, :] . Wv[h dh + d, :] + rowsum * bv
             XgArgs a{};
@@ -683,7 +875,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.alpha = 1.0f;
             a.bias = d.bkv + D; a.bias_sb = dh;
             if (drop) { a.rowscale = d.rowsum; a.rs_sm = H; a.rs_sb = 1; }
-            XCHK((launch_xg<384, 128, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
         }
         // s = dropout(ctx Wo^T + bo) + x                                          (bert_model.py:361-363)
         m3ae_gemm_desc o = g;
@@ -708,13 +900,13 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.C = Kp; a.ldc = D; a.c_sb = (int64_t)T * D;
             a.rdiv = T; a.rmul = R;
             a.alpha = scale;
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
             // V'[b, h*T + j, :] = v_h Wo[:, h]^T
             a.A = (const bf16_t*)d.proj + D;
             a.B = (const bf16_t*)d.wo; a.ldb = D; a.b_sb = dh;               // Wo [n][h dh + d]
             a.C = Vp;
             a.alpha = 1.0f;
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
         }
         {
             const int n = B * T * H;
@@ -733,7 +925,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.colbias = d.colbias; a.cb_sb = R;
             a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
             a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
         }
         {   // s = dropout(drop(P) V' + bo) + x
             XgArgs a{};
@@ -744,9 +936,16 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.bias = d.bo;
             a.residual = (const bf16_t*)d.x;
             a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
-            XCHK((launch_xg<128, 384, 2, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
+            if (D == 768) {   // whole rows per workgroup: LayerNorm in the epilogue, no pre-LayerNorm round trip
+                a.C = (bf16_t*)d.out; a.C2 = (bf16_t*)d.s;
+                a.ln_g = d.ln_g; a.ln_b = d.ln_b; a.ln_eps = d.ln_eps; a.mean_out = d.mean; a.rstd_out = d.rstd;
+                return launch_xg<64, 768, 1, 3, 4, FORM_K, FORM_T, XE_DENSE_LN>(a, B, s);
+            }
+            if (!d.s) return M3AE_ERR_ARG;
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
         }
     }
+    if (!d.s) return M3AE_ERR_ARG;
     // out = LayerNorm(s)                                                          (bert_model.py:363)
     return m3ae_layernorm_fwd(d.s, d.ln_g, d.ln_b, d.out, d.mean, d.rstd, (int64_t)B * Lq, D, d.ln_eps, M3AE_BF16,
                               M3AE_ACT_NONE, 0, stream);
