@@ -27,7 +27,7 @@
 namespace {
 
 enum { FORM_K = 0, FORM_T = 1 };
-enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3, XE_DENSE_LN = 4 };
+enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3 };
 
 struct XgArgs {
     const bf16_t* A; int64_t lda, a_sb;    // FORM_K: [M][K] (lda = row stride); FORM_T: [K][M] (lda = stride of a k row)
@@ -46,8 +46,6 @@ struct XgArgs {
     int n_valid;                           // XE_SOFTMAXROW: columns >= n_valid are masked out (P = 0)
     DropState drop; int has_drop;
     int H, Lq, drop_ld;                    // dropout index convention of m3ae_attn_desc: ((b*H + h)*Lq + q) * ld + k
-    const float* ln_g; const float* ln_b; float ln_eps;   // XE_DENSE_LN: LayerNorm over the tile's whole rows (BN == N)
-    float* mean_out; float* rstd_out;      // XE_DENSE_LN: [batch * M + m] statistics (nullptr: not kept)
     int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
 };
 
@@ -151,7 +149,10 @@ template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFOR
 __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(XgArgs a) {
     constexpr int WAVES_N = 8 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
     constexpr int NST = NLOAD ? NLOAD : 8;   // waves that issue the LDS-DMA pieces
+    // pieces per staging wave and chunk; an operand with fewer pieces than staging waves (BM = 64 with 8 of them) is staged by
+    // the first waves only and left out of the counted vmcnt (those waves then wait for a little more than they must)
     constexpr int GA = BM / 16 / NST, GB = BN / 16 / NST, G = GA + GB, DEPTH = NSLOT - 1;
+    static_assert(GB >= 1 && (BM / 16) % (GA ? NST : 1) == 0 && (BN / 16) % NST == 0, "pieces per staging wave");
     constexpr int A_BYTES = BM * 64, SLOT = (BM + BN) * 64;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && WM % 16 == 0 && WN % 16 == 0 && DEPTH >= 2 && DEPTH <= 3 && (NLOAD == 0 || NLOAD == 4), "tile shape");
     static_assert((AFORM == FORM_K || BM % 128 == 0) && (BFORM == FORM_K || BN % 128 == 0), "T-form operands come in 128-column panels");
@@ -181,8 +182,10 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
         }
     };
     auto stage_a = [&](int c, char* slot) {
-        if constexpr (AFORM == FORM_K) nt_stage<32, GA, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
-        else {
+        if constexpr (AFORM == FORM_K) {
+            if constexpr (GA >= 1) nt_stage<32, GA, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
+            else if (lw < BM / 16) nt_stage<32, 1, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
+        } else {
 #pragma unroll
             for (int p = 0; p < BM / 128; ++p)
 #pragma unroll
@@ -446,123 +449,6 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-    } else if constexpr (EPI == XE_DENSE_LN) {
-        // BertSelfOutput whole (bert_model.py:360-364): LayerNorm(dropout(dense) + residual) with the tile covering whole
-        // rows (WAVES_M == 1, BN == N): no pre-LayerNorm tensor goes to memory and comes back (the separate LayerNorm pass read
-        // and wrote 227 MB each at B = 256).  The residual tile is DMA-staged into the (free) ring as [BM][N] bf16, its 16-B
-        // chunks XOR-swizzled by the row so that the accumulator-layout reads (16 rows x 8 B per instruction) are conflict
-        // free; statistics in two passes (mean, centred variance: fp32, as norm.hip) through an LDS exchange between the waves.
-        static_assert(WAVES_M == 1, "whole rows per workgroup");
-        constexpr int XRES_BYTES = BM * BN * 2, NPIECE = XRES_BYTES / 1024, CPRW = BN / 8;   // chunks per row
-        static_assert(NPIECE % 8 == 0 && XRES_BYTES + 8 * SLAB_STRIDE + 4 * 8 * BM <= NSLOT * SLOT, "epilogue LDS budget");
-        char* xres = smem;
-        char* slab2 = smem + XRES_BYTES + wave * SLAB_STRIDE;
-        float* red2 = (float*)(smem + XRES_BYTES + 8 * SLAB_STRIDE);   // [8 waves][BM]
-        const int64_t grow0 = (int64_t)bi * a.M;
-        if (a.residual) {
-#pragma unroll
-            for (int q = 0; q < NPIECE / 8; ++q) {
-                const int piece = q * 8 + wave;
-                const int byte = piece * 1024 + lane * 16;
-                const int row = byte / (BN * 2), ch = (byte - row * (BN * 2)) >> 4;
-                int m = m0 + row;
-                m = m < a.M ? m : a.M - 1;
-                glds16(a.residual + (grow0 + m) * a.ldc + ((ch ^ (row & 15)) << 3), xres + piece * 1024);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float rsum[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rl_ = i * 16 + (lane & 15);
-            const int64_t gm = grow0 + mw + 16 * i;
-            float s_ = 0.f;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nw + 16 * j;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (a.bias) {
-                    const f32x4 b4 = *(const f32x4*)(a.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += b4[r];
-                }
-                if (a.has_drop) drop_apply4(a.drop, (uint64_t)(gm * a.N + n), v);
-                if (a.residual) {
-                    const int ch = n >> 3;
-                    const u32x2 rr = *(const u32x2*)(xres + rl_ * (BN * 2) + ((ch ^ (rl_ & 15)) << 4) + (n & 7) * 2);
-                    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; s_ += v[r]; }
-            }
-            rsum[i] = quad16_sum(s_);
-            if (lane < 16) red2[wc * BM + rl_] = rsum[i];
-        }
-        __syncthreads();
-        float mean[MI], rstd[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rl_ = i * 16 + (lane & 15);
-            float t_ = red2[rl_];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) t_ += red2[w * BM + rl_];
-            mean[i] = t_ * (1.0f / (float)BN);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rl_ = i * 16 + (lane & 15);
-            float q_ = 0.f;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float dlt = acc[i][j][r] - mean[i]; q_ = fmaf(dlt, dlt, q_); }
-            q_ = quad16_sum(q_);
-            if (lane < 16) red2[wc * BM + rl_] = q_;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rl_ = i * 16 + (lane & 15);
-            float t_ = red2[rl_];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) t_ += red2[w * BM + rl_];
-            rstd[i] = rsqrtf(t_ * (1.0f / (float)BN) + a.ln_eps);
-            const int m = mw + 16 * i;
-            if (wc == 0 && lane < 16 && m < a.M) {
-                if (a.mean_out) a.mean_out[grow0 + m] = mean[i];
-                if (a.rstd_out) a.rstd_out[grow0 + m] = rstd[i];
-            }
-        }
-#pragma unroll
-        for (int out = 0; out < 2; ++out) {       // out 0: LayerNorm output; out 1: the pre-LayerNorm sum (kept for a backward)
-            if (out == 1 && a.C2 == nullptr) break;
-            bf16_t* dst = out == 0 ? a.C : a.C2;
-#pragma unroll
-            for (int ps = 0; ps < MI / 2; ++ps) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    const int i = 2 * ps + ii;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int n = nw + 16 * j;
-                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        if (out == 0) {
-                            const f32x4 g4 = *(const f32x4*)(a.ln_g + n), b4 = *(const f32x4*)(a.ln_b + n);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaf((v[r] - mean[i]) * rstd[i], g4[r], b4[r]);
-                        }
-                        slab_put_bf16<WN>(slab2, lane, ii, j, v);
-                    }
-                }
-                slab_store_bf16<WN>(slab2, lane, ncols_ok, [&](int row) -> bf16_t* {
-                    const int m = mw0 + 32 * ps + row;
-                    return m < a.M ? dst + (grow0 + m) * a.ldc + nw0 : nullptr;
-                });
-            }
-        }
     } else if constexpr (EPI == XE_SOFTMAX32) {
         // image queries: column n = h * 32 + j; one softmax per (row, head) = one pair of 16-column blocks of this wave
         static_assert(NJ % 2 == 0, "heads are pairs of 16-column blocks");
@@ -818,7 +704,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
     const int Lq = (int)d.Lq, Lk = (int)d.Lk;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool drop = d.dropout_p > 0.f;
-    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
+    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.s || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
 
     m3ae_gemm_desc g{};
     g.batch1 = g.batch2 = 1;
@@ -936,16 +822,11 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.bias = d.bo;
             a.residual = (const bf16_t*)d.x;
             a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
-            if (D == 768) {   // whole rows per workgroup: LayerNorm in the epilogue, no pre-LayerNorm round trip
-                a.C = (bf16_t*)d.out; a.C2 = (bf16_t*)d.s;
-                a.ln_g = d.ln_g; a.ln_b = d.ln_b; a.ln_eps = d.ln_eps; a.mean_out = d.mean; a.rstd_out = d.rstd;
-                return launch_xg<64, 768, 1, 3, 4, FORM_K, FORM_T, XE_DENSE_LN>(a, B, s);
-            }
-            if (!d.s) return M3AE_ERR_ARG;
+            // (LayerNorm in this kernel's epilogue -- a 64 x 768 whole-row tile -- was built and measured: the 13-us epilogue of a
+            // tile that nothing overlaps costs what the separate 106-us LayerNorm pass costs, 310 vs 326 us: not kept)
             XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
         }
     }
-    if (!d.s) return M3AE_ERR_ARG;
     // out = LayerNorm(s)                                                          (bert_model.py:363)
     return m3ae_layernorm_fwd(d.s, d.ln_g, d.ln_b, d.out, d.mean, d.rstd, (int64_t)B * Lq, D, d.ln_eps, M3AE_BF16,
                               M3AE_ACT_NONE, 0, stream);
