@@ -161,10 +161,31 @@ typedef struct {
     void* s;
     void* out;
     float *mean, *rstd;
+    /* ---- backward only (m3ae_xattn_bwd): the forward's fields above hold what the forward wrote ---- */
+    const void* d_out;            /* [B*Lq, D] gradient of `out` */
+    void* dx;                     /* [B*Lq, D] gradient of x (residual branch included) */
+    void* dy;                     /* [B*Lk, D] gradient of y */
+    /* parameter gradients, fp32, ACCUMULATED: weights [D, D] / [2D, D] like the parameters, biases [D] / [2D] */
+    float *g_wq, *g_wkv, *g_wo, *g_bq, *g_bkv, *g_bo, *g_ln_g, *g_ln_b;
+    /* caller-owned scratch */
+    void* ws_ds;                  /* [B*Lq, D]                       gradient of s */
+    void* ws_dsd;                 /* [B*Lq, D]   (dropout_p > 0)     gradient of the dense output before the hidden dropout */
+    void* ws_dscores;             /* like `probs`                    gradient of the scores */
+    void* ws_dprime;              /* like `prime`                    gradient of Q' (dir 0) / K', V' (dir 1) */
+    void* ws_dproj;               /* like `proj`                     gradient of q (dir 0) / k | v (dir 1) */
+    void* ws_dz;                  /* dir 0: [B, Lq*H, D]             gradient of zctx */
+    void* ws_dctx;                /* dir 0: [B*Lq, D]                gradient of ctx */
+    float* ws_vec;                /* fp32 [3 * B * H * 32] */
+    float* ws_ln;                 /* fp32 [2 * m3ae_layernorm_bwd_blocks(B*Lq) * D] */
 } m3ae_xattn_desc;
 int m3ae_xattn_supported(const m3ae_xattn_desc* d);   /* 1 if the fused kernels cover these shapes */
 int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d);
 int m3ae_xattn_fwd(const m3ae_xattn_desc* d, void* stream);
+/* Backward of m3ae_xattn_fwd in the same absorbed form: two more per-sample products per direction (the gradient of the
+ * scores with the softmax backward in its epilogue, the gradients of the absorbed operands), the other stream's gradient,
+ * and the per-head weight gradients as split-K fp32 atomics.  d(b_k) is exactly zero (b_k drops out of the softmax) and is
+ * not touched.  Dropout masks are regenerated from the forward's seeds. */
+int m3ae_xattn_bwd(const m3ae_xattn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm (biased variance, eps inside the sqrt, fp32 statistics), optional fused activation on the output.

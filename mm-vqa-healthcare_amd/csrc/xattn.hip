@@ -27,7 +27,7 @@
 namespace {
 
 enum { FORM_K = 0, FORM_T = 1 };
-enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3 };
+enum { XE_STORE = 0, XE_DENSE = 1, XE_SOFTMAX32 = 2, XE_SOFTMAXROW = 3, XE_ATOMIC = 4, XE_DSOFT = 5 };
 
 struct XgArgs {
     const bf16_t* A; int64_t lda, a_sb;    // FORM_K: [M][K] (lda = row stride); FORM_T: [K][M] (lda = stride of a k row)
@@ -39,24 +39,53 @@ struct XgArgs {
     int rdiv, rmul;                        // XE_STORE row map: crow = (m / rdiv) * rmul + m % rdiv   (rdiv = 0: identity)
     float alpha;
     const float* bias; int64_t bias_sb;    // [N] (+ batch * bias_sb)
-    const float* rowscale; int64_t rs_sm, rs_sb;   // XE_STORE: bias is multiplied by rowscale[m * rs_sm + batch * rs_sb]
+    const float* rowscale; int64_t rs_sm, rs_sb;   // XE_STORE: bias is multiplied by rowscale[map(m) * rs_sm + batch * rs_sb]
+    int rs_div, rs_mul;                    //           map(m) = (m / rs_div) * rs_mul + m % rs_div   (rs_div = 0: m)
+    int b_rows;                            // rows of a K-contiguous B that exist (0: N); rows beyond are clamped duplicates
     const bf16_t* residual;                // XE_DENSE: [batch * M + m][ldc]
     const float* colbias; int64_t cb_sb;   // softmax epilogues: additive [batch][N] (nullptr: none)
     float* rowsum_out;                     // XE_SOFTMAXROW with dropout: [batch][M] row sums of the dropped probabilities
     int n_valid;                           // XE_SOFTMAXROW: columns >= n_valid are masked out (P = 0)
     DropState drop; int has_drop;
     int H, Lq, drop_ld;                    // dropout index convention of m3ae_attn_desc: ((b*H + h)*Lq + q) * ld + k
+    // memory-row maps of the operands, row -> (row / div) * mul + row % div (div = 0: identity): the rows of a K-contiguous
+    // operand, the REDUCTION rows of a reduction-strided one (per-head views of the [B][H*T][D] intermediates)
+    int a_div, a_mul, b_div, b_mul;
+    int ksplit, kchunks;                   // split of the reduction over workgroups (XE_ATOMIC): `kchunks` 32-deep chunks each
+    float* Cf;                             // XE_ATOMIC: fp32 [batch][M][ldc], += alpha * acc
+    int accumulate;                        // XE_STORE: C += (bf16 read-modify-write)
+    const bf16_t* P;                       // XE_DSOFT: the probabilities, laid out like C
+    const float* delta; const float* radd; // XE_DSOFT: per-row [batch][M] softmax-backward term / addend to dP (nullptr: 32-column groups / 0)
+    int drop_mode;                         // XE_DSOFT dropout index: 0: row = t*H + h, key = n;  1: head = n / 32, query = m, key = n % 32
     int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
 };
 
+DEVINL int64_t map_row(int64_t r, int div, int mul) { return div ? (r / div) * (int64_t)mul + r % div : r; }
+
+// nt_stage (mfma_tiles.h) with a memory-row map
+template <int SEGS_PER_WAVE, int NWAVES>
+DEVINL void nt_stage_m(const bf16_t* G, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile, int wave, int lane,
+                       int div, int mul) {
+#pragma unroll
+    for (int q = 0; q < SEGS_PER_WAVE; ++q) {
+        const int seg = q * NWAVES + wave;
+        const int row = seg * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ nt_swz<32>(row);
+        int64_t grow = row0 + row;
+        grow = grow < nrows ? grow : nrows - 1;
+        glds16(G + map_row(grow, div, mul) * ld + k0 + chunk * 8, tile + seg * 1024);
+    }
+}
+
 // one 1-KiB piece (4 rows) of a [32 k-rows][128 cols] panel of a reduction-strided operand; piece = 0..7
 DEVINL void t_stage128(const bf16_t* G, int64_t ld, int r0, int r_end, int col0, int ncols, char* panel, int piece,
-                       int lane) {
+                       int lane, int div = 0, int mul = 0) {
     const int wave = piece;
     const int row = wave * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ tn_swz(row);
     const int grow = r0 + row, col = col0 + chunk * 8;
-    const void* src = (grow < r_end && col < ncols) ? (const void*)(G + (int64_t)grow * ld + col)
+    const int64_t mrow = div ? ((int64_t)(grow / div) * mul + grow % div) : (int64_t)grow;
+    const void* src = (grow < r_end && col < ncols) ? (const void*)(G + mrow * ld + col)
                                                     : (const void*)((const char*)g_m3ae_zero_page + (lane & 15) * 16);
     glds16(src, panel + wave * 1024);
 }
@@ -161,36 +190,41 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const unsigned per_b = (unsigned)(a.tiles_m * a.tiles_n);
+    const unsigned per_t = (unsigned)(a.tiles_m * a.tiles_n), per_b = per_t * (unsigned)(a.ksplit > 1 ? a.ksplit : 1);
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);   // an XCD walks a contiguous range: a sample's tiles share its L2
-    const unsigned bi = wg / per_b, tt = wg - bi * per_b;
+    const unsigned bi = wg / per_b, t2 = wg - bi * per_b;
+    const unsigned ks = t2 / per_t, tt = t2 - ks * per_t;
     const int m0 = (int)(tt / a.tiles_n) * BM, n0 = (int)(tt % a.tiles_n) * BN;
-    const int nc = (a.K + 31) >> 5;
+    const int nc_all = (a.K + 31) >> 5;
+    const int c_first = a.ksplit > 1 ? (int)ks * a.kchunks : 0;   // this workgroup's chunks of the reduction
+    const int nc = a.ksplit > 1 ? (nc_all - c_first < a.kchunks ? nc_all - c_first : a.kchunks) : nc_all;
     XG_STAMP(0);
 
     const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
     const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
     const int lw = NLOAD ? wave - 8 : wave;   // index among the staging waves
     auto stage_b = [&](int c, char* slot) {
-        if constexpr (BFORM == FORM_K) nt_stage<32, GB, NST>(B, a.ldb, n0, a.N, (int64_t)c * 32, slot + A_BYTES, lw, lane);
+        const int cc = c + c_first;
+        if constexpr (BFORM == FORM_K) nt_stage_m<GB, NST>(B, a.ldb, n0, a.b_rows ? a.b_rows : a.N, (int64_t)cc * 32, slot + A_BYTES, lw, lane, a.b_div, a.b_mul);
         else {
 #pragma unroll
             for (int p = 0; p < BN / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(B, a.ldb, c * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane);
+                    t_stage128(B, a.ldb, cc * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane, a.b_div, a.b_mul);
         }
     };
     auto stage_a = [&](int c, char* slot) {
+        const int cc = c + c_first;
         if constexpr (AFORM == FORM_K) {
-            if constexpr (GA >= 1) nt_stage<32, GA, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
-            else if (lw < BM / 16) nt_stage<32, 1, NST>(A, a.lda, m0, a.M, (int64_t)c * 32, slot, lw, lane);
+            if constexpr (GA >= 1) nt_stage_m<GA, NST>(A, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
+            else if (lw < BM / 16) nt_stage_m<1, NST>(A, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
         } else {
 #pragma unroll
             for (int p = 0; p < BM / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(A, a.lda, c * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane);
+                    t_stage128(A, a.lda, cc * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane, a.a_div, a.a_mul);
         }
     };
     auto stage = [&](int c, char* slot) { stage_b(c, slot); stage_a(c, slot); };
@@ -363,7 +397,7 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
     const int mw = mw0 + (lane & 15);                     // + 16 i: this lane's row in the accumulator layout
     const int nw = nw0 + 4 * (lane >> 4);                 // + 16 j
     const int ncols_ok = a.N - nw0;                       // columns of the sub-tile inside the matrix (multiple of 8)
-    constexpr int SLAB_STRIDE = Slab<WN, EPI == XE_DENSE ? 4 : 2>::BYTES;   // per-wave slab region
+    constexpr int SLAB_STRIDE = Slab<WN, (EPI == XE_DENSE || EPI == XE_ATOMIC) ? 4 : 2>::BYTES;   // per-wave slab region (XE_DSOFT: 16-row fp32 passes, half of the fp32 size = the bf16 size)
     char* slab = smem + wave * SLAB_STRIDE;
     static_assert(8 * SLAB_STRIDE + 4 * WAVES_N * BM <= NSLOT * SLOT, "slabs + reduction scratch fit the ring");
     float* red = (float*)(smem + 8 * SLAB_STRIDE);        // [WAVES_N][BM] cross-wave reduction scratch (XE_SOFTMAXROW)
@@ -376,7 +410,7 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * ps + ii, m = mw + 16 * i;
-                const float rs = (a.rowscale && m < a.M) ? a.rowscale[(int64_t)m * a.rs_sm + (int64_t)bi * a.rs_sb] : 1.0f;
+                const float rs = (a.rowscale && m < a.M) ? a.rowscale[map_row(m, a.rs_div, a.rs_mul) * a.rs_sm + (int64_t)bi * a.rs_sb] : 1.0f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int n = nw + 16 * j;
@@ -389,12 +423,33 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
                     slab_put_bf16<WN>(slab, lane, ii, j, v);
                 }
             }
-            slab_store_bf16<WN>(slab, lane, ncols_ok, [&](int row) -> bf16_t* {
+            auto rowptr = [&](int row) -> bf16_t* {
                 const int m = mw0 + 32 * ps + row;
                 if (m >= a.M) return nullptr;
                 const int64_t crow = a.rdiv ? (int64_t)(m / a.rdiv) * a.rmul + (m % a.rdiv) : (int64_t)m;
                 return C + crow * a.ldc + nw0;
-            });
+            };
+            if (!a.accumulate) slab_store_bf16<WN>(slab, lane, ncols_ok, rowptr);
+            else {   // C += : bf16 read-modify-write along the rows (second product into the same output)
+                using S2 = Slab<WN, 2>;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < S2::PPL; ++t) {
+                    const int piece = lane + 64 * t, row = piece / S2::PR, c8 = piece - row * S2::PR;
+                    const u32x4 v = *(const u32x4*)(slab + row * S2::RS + c8 * 16);
+                    bf16_t* p = rowptr(row);
+                    if (p != nullptr && c8 * 8 < ncols_ok) {
+                        const u32x4 o = *(const u32x4*)(p + c8 * 8);
+                        u32x4 r;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            r[q] = pack2bf(__uint_as_float(v[q] << 16) + __uint_as_float(o[q] << 16),
+                                           __uint_as_float(v[q] & 0xffff0000u) + __uint_as_float(o[q] & 0xffff0000u));
+                        *(u32x4*)(p + c8 * 8) = r;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
     } else if constexpr (EPI == XE_DENSE) {
         // BertSelfOutput (bert_model.py:360-364) up to the LayerNorm: dropout(dense) + residual; dropout index = the GEMM
@@ -446,6 +501,92 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
                 if (m < a.M && c8 * 8 < ncols_ok)
                     *(u32x4*)(a.C + ((int64_t)bi * a.M + m) * a.ldc + nw0 + c8 * 8) =
                         (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (EPI == XE_ATOMIC) {
+        // split-K weight gradients: fp32 += alpha * acc, through the slab so that a wave-instruction adds two 128-B row
+        // segments (the full-rate shape of global_atomic_add_f32; 64 scattered dwords run ~17x slower)
+        using S = Slab<WN, 4>;
+        float* Cf = a.Cf + (int64_t)bi * a.c_sb;
+#pragma unroll
+        for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x4 v = acc[2 * ps + ii][j];
+                    slab_put_f32<WN>(slab, lane, ii, j, (f32x4){v[0] * a.alpha, v[1] * a.alpha, v[2] * a.alpha, v[3] * a.alpha});
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_assert(WN % 32 == 0, "32-float row segments");
+#pragma unroll 4
+            for (int t = 0; t < 32 * WN / 64; ++t) {
+                const int e = lane + 64 * t, seg = e >> 5, row = seg / (WN / 32), col = (seg % (WN / 32)) * 32 + (e & 31);
+                const int m = mw0 + 32 * ps + row, n = nw0 + col;
+                const float v = *(const float*)(slab + row * S::RS + col * 4);
+                if (m < a.M && n < a.N) atomicAdd(Cf + (int64_t)m * a.ldc + n, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (EPI == XE_DSOFT) {
+        // softmax backward in the row-contiguous layout: acc = dL/d(dropped probabilities); dS = P (dP - delta) with
+        // dP = keep / (1 - p) (acc + radd[row]) and delta = sum_k P dP over the softmax's extent -- given per row (whole-row
+        // softmax: delta = dZ . Z + radd * rowsum, the flash-attention identity, computed by xattn_rowdot_kernel) or summed
+        // here over each 32-column group (4 adjacent lanes of the row layout).  16-row fp32 slab passes.
+        constexpr int RS = WN * 4 + 16, PR = WN / 8, PPL = 16 * PR / 64;
+        static_assert((16 * PR) % 64 == 0 && 16 * RS <= SLAB_STRIDE * 2 && PR % 4 == 0, "16-row fp32 slab pass");
+        char* slab16 = smem + wave * (16 * RS);
+        static_assert(8 * 16 * RS <= NSLOT * SLOT, "slabs fit the ring");
+        bf16_t* dS = a.C + (int64_t)bi * a.c_sb;
+        const bf16_t* Pp = a.P + (int64_t)bi * a.c_sb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                *(f32x4*)(slab16 + (lane & 15) * RS + (16 * j + 4 * (lane >> 4)) * 4) = acc[i][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < PPL; ++t) {
+                const int piece = lane + 64 * t, row = piece / PR, c8 = piece - row * PR;
+                const int m = mw0 + 16 * i + row, n = nw0 + c8 * 8;
+                const bool ok = m < a.M && n < a.N;
+                const f32x4 v0 = *(const f32x4*)(slab16 + row * RS + c8 * 32);
+                const f32x4 v1 = *(const f32x4*)(slab16 + row * RS + c8 * 32 + 16);
+                float dp[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                u32x4 pr = {0u, 0u, 0u, 0u};
+                if (ok) pr = *(const u32x4*)(Pp + (int64_t)m * a.ldc + n);
+                float p[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { p[2 * q] = __uint_as_float(pr[q] << 16); p[2 * q + 1] = __uint_as_float(pr[q] & 0xffff0000u); }
+                const int64_t gr = (int64_t)bi * a.M + m;
+                const float radd = (a.radd && ok) ? a.radd[gr] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dp[e] += radd;
+                if (a.has_drop) {
+                    uint64_t base;
+                    int k0;
+                    if (a.drop_mode == 0) { base = ((uint64_t)((int64_t)bi * a.H + (m % a.H)) * a.Lq + (m / a.H)) * a.drop_ld; k0 = n; }
+                    else { base = ((uint64_t)((int64_t)bi * a.H + (n >> 5)) * a.Lq + m) * a.drop_ld; k0 = n & 31; }
+                    drop_apply4(a.drop, base + k0, dp);
+                    drop_apply4(a.drop, base + k0 + 4, dp + 4);
+                }
+                float dl;
+                if (a.delta) dl = ok ? a.delta[gr] : 0.f;
+                else {
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part = fmaf(p[e], dp[e], part);
+                    part += __shfl_xor(part, 1, 64);
+                    dl = part + __shfl_xor(part, 2, 64);
+                }
+                if (ok) {
+                    float ds_[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ds_[e] = p[e] * (dp[e] - dl);
+                    *(u32x4*)(dS + (int64_t)m * a.ldc + n) =
+                        (u32x4){pack2bf(ds_[0], ds_[1]), pack2bf(ds_[2], ds_[3]), pack2bf(ds_[4], ds_[5]), pack2bf(ds_[6], ds_[7])};
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -648,7 +789,7 @@ int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
 #ifdef M3AE_XG_TRACE
     a.trace_slot = g_trace_next++ & 7;
 #endif
-    const unsigned grid = (unsigned)(nbatch * a.tiles_m * a.tiles_n);
+    const unsigned grid = (unsigned)(nbatch * a.tiles_m * a.tiles_n * (a.ksplit > 1 ? a.ksplit : 1));
     hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI>), dim3(grid), dim3(NLOAD ? 768 : 512), lds, s, a);
     return hip_launch_status();
 }
@@ -671,6 +812,75 @@ __global__ __launch_bounds__(256) void xattn_colbias_kernel(const bf16_t* k, int
         }
     }
     cb[(int64_t)b * H * T + h * T + j] = s * scale + (mask ? mask[b * T + j] : 0.f);
+}
+
+
+// dcb[b][n] = scale * sum_i dS[b][i][n]   (dir 1: gradient of the per-column score bias c)
+__global__ __launch_bounds__(256) void xattn_colsum_kernel(const bf16_t* dS, float* out, int I, int R, float scale) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (n < R) {
+        const bf16_t* p = dS + (int64_t)b * I * R + n;
+        for (int i = sub; i < I; i += 4) acc += bf2f(p[(int64_t)i * R]);
+    }
+    part[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && n < R) out[(int64_t)b * R + n] = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// out[h dh + d] += sum_m w[(m / T) R + (m % T) w_t + h w_h] * X[m][h dh + d]      (bias gradients of the absorbed projections;
+// w == nullptr: weights 1).  grid (H, row blocks of 256), block 256 = dh columns x (256 / dh) row lanes.
+__global__ __launch_bounds__(256) void xattn_headvec_kernel(const float* w, const bf16_t* X, int64_t ldx, float* out, int Mrows,
+                                                            int T, int R, int w_t, int w_h, int dh) {
+    __shared__ float part[256];
+    const int h = blockIdx.x, d = threadIdx.x % dh, sub = threadIdx.x / dh, nsub = 256 / dh;
+    const int r0 = blockIdx.y * 256, r1 = r0 + 256 < Mrows ? r0 + 256 : Mrows;
+    float acc = 0.f;
+    if (sub < nsub)
+        for (int m = r0 + sub; m < r1; m += nsub) {
+            const float wt = w ? w[(int64_t)(m / T) * R + (m % T) * w_t + h * w_h] : 1.0f;
+            acc = fmaf(wt, bf2f(X[(int64_t)m * ldx + h * dh + d]), acc);
+        }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (sub == 0) {
+        for (int q = 1; q < nsub; ++q) acc += part[q * dh + d];
+        atomicAdd(out + h * dh + d, acc);
+    }
+}
+
+// dir 0, one wave per row r = t H + h of sample b:  radd[b][r] = dctx[b T + t][h dh ..] . bv[h dh ..]  (gradient wrt the row sum of the
+// dropped probabilities; only with dropout), delta[b][r] = dZ[b][r][:] . Z[b][r][:] + radd * rowsum
+__global__ __launch_bounds__(256) void xattn_rowdot_kernel(const bf16_t* dZ, const bf16_t* Z, const bf16_t* dctx, const float* bv,
+                                                           const float* rowsum, float* delta, float* radd, int64_t rows, int D,
+                                                           int T, int H, int dh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* a = dZ + row * D;
+    const bf16_t* z = Z + row * D;
+    float acc = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        const u32x4 x = *(const u32x4*)(a + c), y = *(const u32x4*)(z + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = fmaf(__uint_as_float(x[q] << 16), __uint_as_float(y[q] << 16), acc);
+            acc = fmaf(__uint_as_float(x[q] & 0xffff0000u), __uint_as_float(y[q] & 0xffff0000u), acc);
+        }
+    }
+    acc = wave_sum(acc);
+    float ra = 0.f;
+    if (radd) {
+        const int R = T * H, r = (int)(row % R), b = (int)(row / R), t = r / H, h = r % H;
+        float s_ = 0.f;
+        for (int d = lane; d < dh; d += 64) s_ = fmaf(bf2f(dctx[((int64_t)b * T + t) * D + h * dh + d]), bv[h * dh + d], s_);
+        ra = wave_sum(s_);
+    }
+    if (lane == 0) {
+        if (radd) radd[row] = ra;
+        delta[row] = acc + (radd ? ra * rowsum[row] : 0.f);
+    }
 }
 
 }  // namespace
@@ -830,4 +1040,239 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
     // out = LayerNorm(s)                                                          (bert_model.py:363)
     return m3ae_layernorm_fwd(d.s, d.ln_g, d.ln_b, d.out, d.mean, d.rstd, (int64_t)B * Lq, D, d.ln_eps, M3AE_BF16,
                               M3AE_ACT_NONE, 0, stream);
+}
+
+namespace {
+// split of a reduction of `nchunks` 32-deep chunks so that the launch has ~256 workgroups
+void pick_split(XgArgs& a, int nchunks, int tiles) {
+    int ks = 256 / (tiles > 0 ? tiles : 1);
+    if (ks > nchunks / 8) ks = nchunks / 8;     // >= 8 chunks (256 reduction rows) per workgroup
+    if (ks < 1) ks = 1;
+    a.kchunks = (nchunks + ks - 1) / ks;
+    a.ksplit = (nchunks + a.kchunks - 1) / a.kchunks;
+}
+}  // namespace
+
+extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
+    if (!dp || !m3ae_xattn_supported(dp)) return M3AE_ERR_UNSUPPORTED;
+    const m3ae_xattn_desc& d = *dp;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)d.B, H = (int)d.H, D = (int)d.D, dh = D / H;
+    const int Lq = (int)d.Lq, Lk = (int)d.Lk;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const bool drop = d.dropout_p > 0.f;
+    if (!d.d_out || !d.dx || !d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.s || !d.mean || !d.rstd || !d.ws_ds ||
+        !d.ws_dscores || !d.ws_dprime || !d.ws_dproj || !d.ws_vec || !d.ws_ln || (drop && (!d.probs_drop || !d.ws_dsd)) ||
+        !d.g_wq || !d.g_wkv || !d.g_wo || !d.g_bq || !d.g_bkv || !d.g_bo)
+        return M3AE_ERR_ARG;
+    const int64_t Mq = (int64_t)B * Lq;
+    // LayerNorm backward: ds (gradient of the pre-LayerNorm sum = residual branch) and dsd (through the hidden dropout)
+    const void* dsd = d.ws_ds;
+    if (drop) {
+        XCHK(m3ae_layernorm_bwd_drop(d.d_out, d.s, d.ln_g, d.ln_b, d.mean, d.rstd, d.ws_ds, d.ws_dsd, d.dropout_p, d.seed_hidden,
+                                     d.g_ln_g, d.g_ln_b, d.ws_ln, Mq, D, M3AE_BF16, stream));
+        dsd = d.ws_dsd;
+    } else {
+        XCHK(m3ae_layernorm_bwd(d.d_out, d.s, d.ln_g, d.ln_b, d.mean, d.rstd, d.ws_ds, nullptr, d.g_ln_g, d.g_ln_b, d.ws_ln, Mq, D,
+                                M3AE_BF16, M3AE_ACT_NONE, 0, stream));
+    }
+    const bf16_t* Pd = (const bf16_t*)(drop ? d.probs_drop : d.probs);
+    m3ae_gemm_desc g{};
+    g.batch1 = g.batch2 = 1;
+    g.dtype_a = g.dtype_b = M3AE_BF16;
+    g.alpha = 1.0f;
+
+    if (d.dir == 1) {
+        const int I = Lq, T = Lk, R = H * T;
+        if (!d.colbias) return M3AE_ERR_ARG;
+        const bf16_t* Kp = (const bf16_t*)d.prime;
+        const bf16_t* Vp = Kp + (int64_t)B * R * D;
+        bf16_t* dKp = (bf16_t*)d.ws_dprime;
+        bf16_t* dVp = dKp + (int64_t)B * R * D;
+        bf16_t* dS = (bf16_t*)d.ws_dscores;
+        bf16_t* dkv = (bf16_t*)d.ws_dproj;
+        float* dcb = d.ws_vec;
+        XCHK(m3ae_colsum(dsd, d.g_bo, Mq, D, D, M3AE_BF16, 1, stream));
+        {   // dS = softmax'( (dsd V'^T) ) per 32-key group, attention dropout regenerated
+            XgArgs a{};
+            a.A = (const bf16_t*)dsd; a.lda = D; a.a_sb = (int64_t)I * D;
+            a.B = Vp; a.ldb = D; a.b_sb = (int64_t)R * D;
+            a.M = I; a.N = R; a.K = D;
+            a.C = dS; a.ldc = R; a.c_sb = (int64_t)I * R;
+            a.P = (const bf16_t*)d.probs;
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+            a.drop_mode = 1; a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
+        }
+        {   // dV' = drop(P)^T dsd ; dK' = dS^T x      (reductions over the image tokens)
+            XgArgs a{};
+            a.A = Pd; a.lda = R; a.a_sb = (int64_t)I * R;
+            a.B = (const bf16_t*)dsd; a.ldb = D; a.b_sb = (int64_t)I * D;
+            a.M = R; a.N = D; a.K = I;
+            a.C = dVp; a.ldc = D; a.c_sb = (int64_t)R * D; a.alpha = 1.0f;
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
+            a.A = dS; a.B = (const bf16_t*)d.x; a.C = dKp;
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
+        }
+        {   // dx = dS K' + ds
+            XgArgs a{};
+            a.A = dS; a.lda = R; a.a_sb = (int64_t)I * R;
+            a.B = Kp; a.ldb = D; a.b_sb = (int64_t)R * D;
+            a.M = I; a.N = D; a.K = R;
+            a.C = (bf16_t*)d.dx; a.ldc = D;
+            a.residual = (const bf16_t*)d.ws_ds;
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
+        }
+        hipLaunchKernelGGL(xattn_colsum_kernel, dim3((R + 63) / 64, B), dim3(256), 0, s, dS, dcb, I, R, scale);
+        XCHK(hip_launch_status());
+        {   // per head: dk_h = scale dK'_h Wq_h^T + dcb bq_h ; dv_h = dV'_h Wo[:, h]
+            XgArgs a{};
+            a.A = dKp; a.lda = D; a.a_sb = (int64_t)T * D; a.a_div = T; a.a_mul = R;
+            a.B = (const bf16_t*)d.wq; a.ldb = D; a.b_sb = (int64_t)dh * D;
+            a.M = B * T; a.N = dh; a.K = D;
+            a.C = dkv; a.ldc = 2 * D; a.c_sb = dh; a.alpha = scale;
+            a.bias = d.bq; a.bias_sb = dh;
+            a.rowscale = dcb; a.rs_sm = 1; a.rs_sb = T; a.rs_div = T; a.rs_mul = R;
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XgArgs v{};
+            v.A = dVp; v.lda = D; v.a_sb = (int64_t)T * D; v.a_div = T; v.a_mul = R;
+            v.B = (const bf16_t*)d.wo_t; v.ldb = D; v.b_sb = (int64_t)dh * D;
+            v.M = B * T; v.N = dh; v.K = D;
+            v.C = dkv + D; v.ldc = 2 * D; v.c_sb = dh; v.alpha = 1.0f;
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(v, H, s)));
+        }
+        {   // dWq[h] += scale k_h^T dK'_h ; dWo[:, h] += dV'_h^T v_h      (reductions over the B*T text rows: split-K atomics)
+            XgArgs a{};
+            a.A = (const bf16_t*)d.proj; a.lda = 2 * D; a.a_sb = dh;
+            a.B = dKp; a.ldb = D; a.b_sb = (int64_t)T * D; a.b_div = T; a.b_mul = R;
+            a.M = dh; a.N = D; a.K = B * T;
+            a.Cf = d.g_wq; a.ldc = D; a.c_sb = (int64_t)dh * D; a.alpha = scale;
+            pick_split(a, (B * T + 31) / 32, H * ((D + 383) / 384));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(a, H, s)));
+            XgArgs o{};
+            o.A = dVp; o.lda = D; o.a_sb = (int64_t)T * D; o.a_div = T; o.a_mul = R;
+            o.B = (const bf16_t*)d.proj + D; o.ldb = 2 * D; o.b_sb = dh;
+            o.M = D; o.N = dh; o.K = B * T;
+            o.Cf = d.g_wo; o.ldc = D; o.c_sb = dh; o.alpha = 1.0f;
+            pick_split(o, (B * T + 31) / 32, H * ((D + 383) / 384));
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(o, H, s)));
+        }
+        hipLaunchKernelGGL(xattn_headvec_kernel, dim3(H, (B * T + 255) / 256), dim3(256), 0, s, (const float*)dcb,
+                           (const bf16_t*)d.proj, (int64_t)2 * D, d.g_bq, B * T, T, R, 1, T, dh);
+        XCHK(hip_launch_status());
+        // dWkv += dkv^T y (+ bias gradient), dy = dkv Wkv                                     (bert_model.py:276-277 backward)
+        g.M = 2 * D; g.N = D; g.K = (int64_t)B * T;
+        g.A = dkv; g.a_sm = 1; g.a_sk = 2 * D; g.B = d.y; g.b_sk = D; g.b_sn = 1;
+        g.C = d.g_wkv; g.c_sm = D; g.c_sn = 1; g.dtype_c = M3AE_F32; g.accumulate = 1; g.a_rowsum = d.g_bkv;
+        XCHK(m3ae_gemm(&g, stream));
+        if (d.dy) {
+            m3ae_gemm_desc y = g;
+            y.M = (int64_t)B * T; y.N = D; y.K = 2 * D;
+            y.A = dkv; y.a_sm = 2 * D; y.a_sk = 1; y.B = d.wkv_t; y.b_sk = 1; y.b_sn = 2 * D;
+            y.C = d.dy; y.c_sm = D; y.dtype_c = M3AE_BF16; y.accumulate = 0; y.a_rowsum = nullptr;
+            XCHK(m3ae_gemm(&y, stream));
+        }
+        return 0;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- dir 0
+    const int T = Lq, I = Lk, R = T * H;
+    if (!d.zctx || !d.ctx || !d.ws_dz || !d.ws_dctx || (drop && !d.rowsum)) return M3AE_ERR_ARG;
+    bf16_t* dctx = (bf16_t*)d.ws_dctx;
+    bf16_t* dZ = (bf16_t*)d.ws_dz;
+    bf16_t* dS = (bf16_t*)d.ws_dscores;
+    bf16_t* dQp = (bf16_t*)d.ws_dprime;
+    bf16_t* dq = (bf16_t*)d.ws_dproj;
+    float* delta = d.ws_vec;
+    float* radd = drop ? d.ws_vec + (int64_t)B * R : nullptr;
+    // output dense: dWo += dsd^T ctx (+ dbo), dctx = dsd Wo                                         (bert_model.py:361 backward)
+    g.M = D; g.N = D; g.K = Mq;
+    g.A = dsd; g.a_sm = 1; g.a_sk = D; g.B = d.ctx; g.b_sk = D; g.b_sn = 1;
+    g.C = d.g_wo; g.c_sm = D; g.c_sn = 1; g.dtype_c = M3AE_F32; g.accumulate = 1; g.a_rowsum = d.g_bo;
+    XCHK(m3ae_gemm(&g, stream));
+    {
+        m3ae_gemm_desc y = g;
+        y.M = Mq; y.N = D; y.K = D;
+        y.A = dsd; y.a_sm = D; y.a_sk = 1; y.B = d.wo_t; y.b_sk = 1; y.b_sn = D;
+        y.C = dctx; y.c_sm = D; y.dtype_c = M3AE_BF16; y.accumulate = 0; y.a_rowsum = nullptr;
+        XCHK(m3ae_gemm(&y, stream));
+    }
+    {   // dZ[b, t*H + h, :] = dctx_h Wv_h ; dWv[h] += dctx_h^T Z_h ; dbv
+        XgArgs a{};
+        a.A = dctx; a.lda = D; a.a_sb = dh;
+        a.B = (const bf16_t*)d.wkv_t + D; a.ldb = 2 * D; a.b_sb = dh;
+        a.M = B * T; a.N = D; a.K = dh;
+        a.C = dZ; a.ldc = (int64_t)H * D; a.c_sb = D; a.alpha = 1.0f;
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        XgArgs w{};
+        w.A = dctx; w.lda = D; w.a_sb = dh;
+        w.B = (const bf16_t*)d.zctx; w.ldb = (int64_t)H * D; w.b_sb = D;
+        w.M = dh; w.N = D; w.K = B * T;
+        w.Cf = d.g_wkv + (int64_t)D * D; w.ldc = D; w.c_sb = (int64_t)dh * D; w.alpha = 1.0f;
+        pick_split(w, (B * T + 31) / 32, H * ((D + 383) / 384));
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(w, H, s)));
+        hipLaunchKernelGGL(xattn_headvec_kernel, dim3(H, (B * T + 255) / 256), dim3(256), 0, s,
+                           (const float*)(drop ? d.rowsum : nullptr), (const bf16_t*)dctx, (int64_t)D, d.g_bkv + D, B * T, T, R, H, 1, dh);
+        XCHK(hip_launch_status());
+    }
+    hipLaunchKernelGGL(xattn_rowdot_kernel, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, s, (const bf16_t*)dZ,
+                       (const bf16_t*)d.zctx, (const bf16_t*)dctx, d.bkv + D, (const float*)d.rowsum, delta, radd, (int64_t)B * R, D, T, H, dh);
+    XCHK(hip_launch_status());
+    {   // dS = P ((dZ y^T + radd) dropped - delta)
+        XgArgs a{};
+        a.A = dZ; a.lda = D; a.a_sb = (int64_t)R * D;
+        a.B = (const bf16_t*)d.y; a.ldb = D; a.b_sb = (int64_t)I * D; a.b_rows = I;
+        a.M = R; a.N = 640; a.K = D;
+        a.C = dS; a.ldc = 640; a.c_sb = (int64_t)R * 640;
+        a.P = (const bf16_t*)d.probs; a.delta = delta; a.radd = radd;
+        a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+        a.drop_mode = 0; a.H = H; a.Lq = T; a.drop_ld = (int)drop_ld(I);
+        XCHK((launch_xg<128, 640, 2, 3, 0, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
+    }
+    {   // dQ' = dS y
+        XgArgs a{};
+        a.A = dS; a.lda = 640; a.a_sb = (int64_t)R * 640;
+        a.B = (const bf16_t*)d.y; a.ldb = D; a.b_sb = (int64_t)I * D;
+        a.M = R; a.N = D; a.K = I;
+        a.C = dQp; a.ldc = D; a.c_sb = (int64_t)R * D; a.alpha = 1.0f;
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_STORE>(a, B, s)));
+    }
+    if (d.dy) {   // dy = drop(P)^T dZ + dS^T Q'      (reductions over the 384 text-query rows)
+        XgArgs a{};
+        a.A = Pd; a.lda = 640; a.a_sb = (int64_t)R * 640;
+        a.B = dZ; a.ldb = D; a.b_sb = (int64_t)R * D;
+        a.M = I; a.N = D; a.K = R;
+        a.C = (bf16_t*)d.dy; a.ldc = D; a.c_sb = (int64_t)I * D; a.alpha = 1.0f;
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
+        a.A = dS; a.B = (const bf16_t*)d.prime; a.accumulate = 1;
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
+    }
+    {   // per head: dq_h = scale dQ'_h Wk_h^T ; dWk[h] += scale q_h^T dQ'_h
+        XgArgs a{};
+        a.A = dQp; a.lda = (int64_t)H * D; a.a_sb = D;
+        a.B = (const bf16_t*)d.wkv; a.ldb = D; a.b_sb = (int64_t)dh * D;
+        a.M = B * T; a.N = dh; a.K = D;
+        a.C = dq; a.ldc = D; a.c_sb = dh; a.alpha = scale;
+        XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        XgArgs w{};
+        w.A = (const bf16_t*)d.proj; w.lda = D; w.a_sb = dh;
+        w.B = dQp; w.ldb = (int64_t)H * D; w.b_sb = D;
+        w.M = dh; w.N = D; w.K = B * T;
+        w.Cf = d.g_wkv; w.ldc = D; w.c_sb = (int64_t)dh * D; w.alpha = scale;
+        pick_split(w, (B * T + 31) / 32, H * ((D + 383) / 384));
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(w, H, s)));
+    }
+    // query projection: dWq += dq^T x (+ dbq), dx = dq Wq + ds                                   (bert_model.py:263 backward)
+    g.M = D; g.N = D; g.K = Mq;
+    g.A = dq; g.a_sm = 1; g.a_sk = D; g.B = d.x; g.b_sk = D; g.b_sn = 1;
+    g.C = d.g_wq; g.c_sm = D; g.c_sn = 1; g.dtype_c = M3AE_F32; g.accumulate = 1; g.a_rowsum = d.g_bq;
+    XCHK(m3ae_gemm(&g, stream));
+    {
+        m3ae_gemm_desc y = g;
+        y.M = Mq; y.N = D; y.K = D;
+        y.A = dq; y.a_sm = D; y.a_sk = 1; y.B = d.wq_t; y.b_sk = 1; y.b_sn = D;
+        y.C = d.dx; y.c_sm = D; y.dtype_c = M3AE_BF16; y.accumulate = 0; y.a_rowsum = nullptr; y.residual = d.ws_ds;
+        XCHK(m3ae_gemm(&y, stream));
+    }
+    return 0;
 }

@@ -47,6 +47,10 @@ class XattnDesc(C.Structure):
         ("ln_eps", f32), ("dropout_p", f32), ("seed_attn", C.c_uint64), ("seed_hidden", C.c_uint64),
         ("proj", vp), ("prime", vp), ("colbias", vp), ("probs", vp), ("probs_drop", vp), ("rowsum", vp),
         ("zctx", vp), ("ctx", vp), ("s", vp), ("out", vp), ("mean", vp), ("rstd", vp),
+        ("d_out", vp), ("dx", vp), ("dy", vp),
+        ("g_wq", vp), ("g_wkv", vp), ("g_wo", vp), ("g_bq", vp), ("g_bkv", vp), ("g_bo", vp), ("g_ln_g", vp), ("g_ln_b", vp),
+        ("ws_ds", vp), ("ws_dsd", vp), ("ws_dscores", vp), ("ws_dprime", vp), ("ws_dproj", vp), ("ws_dz", vp), ("ws_dctx", vp),
+        ("ws_vec", vp), ("ws_ln", vp),
     ]
 
 
@@ -60,6 +64,7 @@ _SIGS = {
     "m3ae_xattn_supported": (C.c_int, [C.POINTER(XattnDesc)]),
     "m3ae_xattn_probs_ld": (i64, [C.POINTER(XattnDesc)]),
     "m3ae_xattn_fwd": (C.c_int, [C.POINTER(XattnDesc), vp]),
+    "m3ae_xattn_bwd": (C.c_int, [C.POINTER(XattnDesc), vp]),
     "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
     "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),

@@ -566,6 +566,8 @@ def _bdata(b):
 # the fused cross-attention sub-block (csrc/xattn.hip): "auto" = whenever the shapes are covered (bf16, 32 text tokens,
 # <= 640 image tokens); "off" = always the composition q / kv GEMM + flash attention + output GEMM + LayerNorm
 XATTN = os.environ.get("M3AE_XATTN", "auto")
+# training (a backward will be asked): "auto" = fused forward + fused backward, "off" = the composition
+XATTN_TRAIN = os.environ.get("M3AE_XATTN_TRAIN", "auto")
 
 
 def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):
@@ -634,6 +636,47 @@ def xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
     return t["out"], ("xattn", h2, other2, mask, t, seeds, pdrop)
 
 
+def xattn_bwd(dy, saved, B, L, Lo, P, need_dother=True):
+    """Backward of xattn_fwd (m3ae_xattn_bwd): returns (dx, dother); parameter gradients accumulate in place."""
+    _, h2, other2, mask, t, seeds, pdrop = saved
+    dev, D, H = h2.device, h2.shape[1], P.heads
+    d = _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds)
+    for k, v in t.items():
+        setattr(d, k, v.data_ptr())
+    bf = torch.bfloat16
+    e = lambda *shape, dt=bf: torch.empty(shape, dtype=dt, device=dev)
+    dyc = dy.contiguous()
+    dx = e(B * L, D)
+    dother = e(B * Lo, D) if need_dother else None
+    L_ = _lib.lib()
+    w = {"ws_ds": e(B * L, D), "ws_dscores": torch.empty_like(t["probs"]), "ws_dprime": torch.empty_like(t["prime"]),
+         "ws_dproj": torch.empty_like(t["proj"]), "ws_vec": e(3 * B * H * 32, dt=torch.float32),
+         "ws_ln": e(2 * L_.m3ae_layernorm_bwd_blocks(B * L) * D, dt=torch.float32)}
+    if pdrop > 0:
+        w["ws_dsd"] = e(B * L, D)
+    if d.dir == 0:
+        w["ws_dz"] = torch.empty_like(t["zctx"])
+        w["ws_dctx"] = e(B * L, D)
+    for k, v in w.items():
+        setattr(d, k, v.data_ptr())
+    d.d_out, d.dx = dyc.data_ptr(), dx.data_ptr()
+    d.dy = dother.data_ptr() if dother is not None else None
+    train = P.ln.weight.requires_grad
+    grads = {"g_wq": P.w_q, "g_wkv": P.w_kv, "g_wo": P.w_o, "g_bq": P.b_q, "g_bkv": P.b_kv, "g_bo": P.b_o}
+    for k, prm in grads.items():
+        if not prm.requires_grad:
+            raise _lib.M3AEHipError("the fused cross-attention backward needs trainable projection parameters")
+        setattr(d, k, _grad_buf(prm).data_ptr())
+    if train:
+        d.g_ln_g, d.g_ln_b = _grad_buf(P.ln.weight).data_ptr(), _grad_buf(P.ln.bias).data_ptr()
+    e0 = _prof_begin()
+    check(L_.m3ae_xattn_bwd(C.byref(d), _stream()), "m3ae_xattn_bwd")
+    _prof_end(e0, "xattn_bwd", (B, H, L, Lo, D // H))
+    for prm in (P.w_o, P.b_o, P.w_kv, P.b_kv, P.w_q, P.b_q) + ((P.ln.weight, P.ln.bias) if train else ()):
+        _done(prm)
+    return dx, dother
+
+
 def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0, fused_cross=False):
     """BertAttention (bert_model.py:367-413) on 2-D token-major activations. Returns (y, saved).
     pdrop > 0 (training): attention-probability dropout (:334) and hidden dropout on the output dense (:362)."""
@@ -661,6 +704,8 @@ def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0, fused_cross=False):
 
 
 def _attn_sub_bwd(dy, saved, B, L, Lo, P, need_dother=True):
+    if isinstance(saved[0], str):   # ("xattn", ...): the fused sub-block
+        return xattn_bwd(dy, saved, B, L, Lo, P, need_dother)
     h2, other2, proj, o, lse, s, mean, rstd, mask, da, dh = saved
     D = h2.shape[1]
     if dh is not None:
@@ -727,8 +772,8 @@ class BertCrossLayerFn(torch.autograd.Function):
         other2 = other.contiguous().view(B * Lo, other.shape[2])
         pd = getattr(P, "pdrop", 0.0)
         a, s1 = _attn_sub_fwd(h2, B, L, None, L, mask_self, P.attn, pd)
-        # forward-only calls (validation, generation, the frozen encoder under the T5 / decoder heads): the fused
-        # cross-attention sub-block (csrc/xattn.hip); training keeps the composition, whose backward reads K / V
+        # the fused cross-attention sub-block (csrc/xattn.hip) where the shapes are covered: forward-only calls always,
+        # training with its fused backward (ops.XATTN_TRAIN)
         c, s2 = _attn_sub_fwd(a, B, L, other2, Lo, mask_other, P.cross, pd, fused_cross=getattr(P, "fused_cross", False))
         y, s3 = _ffn_sub_fwd(c, P.ffn, pd)
         ctx.saved = (s1, s2, s3)
