@@ -244,6 +244,8 @@ def main():
             if kind.startswith("gemm"):
                 M, N, K, nb = dims
                 fl = 2.0 * M * N * K * nb
+            elif kind.startswith("xattn"):   # the reference formulation's FLOPs of one sub-block, x2 for the backward
+                fl = XATTN_FWD_GFLOP_PER_SAMPLE / 12 * 1e9 * dims[0] * (1.0 if kind == "xattn_fwd" else 2.0)
             else:
                 Bq, H, Lq, Lk, Dh = dims
                 fl = 4.0 * Bq * H * Lq * Lk * Dh * (1.0 if kind == "attn_fwd" else 2.5)

@@ -52,6 +52,8 @@ struct XgArgs {
     // operand, the REDUCTION rows of a reduction-strided one (per-head views of the [B][H*T][D] intermediates)
     int a_div, a_mul, b_div, b_mul;
     int ksplit, kchunks;                   // split of the reduction over workgroups (XE_ATOMIC): `kchunks` 32-deep chunks each
+    const bf16_t* A2; const bf16_t* B2;    // second operand pair (same strides): the reduction continues over it from chunk
+    int k_switch;                          //   `k_switch` on (0: none): C = A B + A2 B2 in one pass (K counts both; K2 = K - 32 k_switch)
     float* Cf;                             // XE_ATOMIC: fp32 [batch][M][ldc], += alpha * acc
     int accumulate;                        // XE_STORE: C += (bf16 read-modify-write)
     const bf16_t* P;                       // XE_DSOFT: the probabilities, laid out like C
@@ -203,28 +205,39 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
     const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
     const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
     const int lw = NLOAD ? wave - 8 : wave;   // index among the staging waves
+    const bf16_t* A2 = a.A2 ? a.A2 + (int64_t)bi * a.a_sb : nullptr;
+    const bf16_t* B2 = a.B2 ? a.B2 + (int64_t)bi * a.b_sb : nullptr;
+    const int k1_rows = a.k_switch ? a.k_switch * 32 : a.K;     // reduction rows of the first pair (T-form bound)
     auto stage_b = [&](int c, char* slot) {
-        const int cc = c + c_first;
-        if constexpr (BFORM == FORM_K) nt_stage_m<GB, NST>(B, a.ldb, n0, a.b_rows ? a.b_rows : a.N, (int64_t)cc * 32, slot + A_BYTES, lw, lane, a.b_div, a.b_mul);
+        int cc = c + c_first;
+        const bool second = a.k_switch && cc >= a.k_switch;
+        const bf16_t* Bp = second ? B2 : B;
+        const int kend = second ? a.K - a.k_switch * 32 : k1_rows;
+        if (second) cc -= a.k_switch;
+        if constexpr (BFORM == FORM_K) nt_stage_m<GB, NST>(Bp, a.ldb, n0, a.b_rows ? a.b_rows : a.N, (int64_t)cc * 32, slot + A_BYTES, lw, lane, a.b_div, a.b_mul);
         else {
 #pragma unroll
             for (int p = 0; p < BN / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(B, a.ldb, cc * 32, a.K, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane, a.b_div, a.b_mul);
+                    t_stage128(Bp, a.ldb, cc * 32, kend, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane, a.b_div, a.b_mul);
         }
     };
     auto stage_a = [&](int c, char* slot) {
-        const int cc = c + c_first;
+        int cc = c + c_first;
+        const bool second = a.k_switch && cc >= a.k_switch;
+        const bf16_t* Ap = second ? A2 : A;
+        const int kend = second ? a.K - a.k_switch * 32 : k1_rows;
+        if (second) cc -= a.k_switch;
         if constexpr (AFORM == FORM_K) {
-            if constexpr (GA >= 1) nt_stage_m<GA, NST>(A, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
-            else if (lw < BM / 16) nt_stage_m<1, NST>(A, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
+            if constexpr (GA >= 1) nt_stage_m<GA, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
+            else if (lw < BM / 16) nt_stage_m<1, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
         } else {
 #pragma unroll
             for (int p = 0; p < BM / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(A, a.lda, cc * 32, a.K, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane, a.a_div, a.a_mul);
+                    t_stage128(Ap, a.lda, cc * 32, kend, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane, a.a_div, a.a_mul);
         }
     };
     auto stage = [&](int c, char* slot) { stage_b(c, slot); stage_a(c, slot); };
@@ -1241,10 +1254,9 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
         XgArgs a{};
         a.A = Pd; a.lda = 640; a.a_sb = (int64_t)R * 640;
         a.B = dZ; a.ldb = D; a.b_sb = (int64_t)R * D;
-        a.M = I; a.N = D; a.K = R;
+        a.M = I; a.N = D; a.K = 2 * R;          // one pass over both reductions: chunks 0 .. R/32 - 1 from (drop(P), dZ), then (dS, Q')
+        a.A2 = dS; a.B2 = (const bf16_t*)d.prime; a.k_switch = R / 32;
         a.C = (bf16_t*)d.dy; a.ldc = D; a.c_sb = (int64_t)I * D; a.alpha = 1.0f;
-        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
-        a.A = dS; a.B = (const bf16_t*)d.prime; a.accumulate = 1;
         XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
     }
     {   // per head: dq_h = scale dQ'_h Wk_h^T ; dWk[h] += scale q_h^T dQ'_h
