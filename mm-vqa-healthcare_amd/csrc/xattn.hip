@@ -828,18 +828,41 @@ __global__ __launch_bounds__(256) void xattn_colbias_kernel(const bf16_t* k, int
 }
 
 
-// dcb[b][n] = scale * sum_i dS[b][i][n]   (dir 1: gradient of the per-column score bias c)
+// dcb[b][n] = scale * sum_i dS[b][i][n]   (dir 1: gradient of the per-column score bias c).  grid (R / 128, B); a workgroup is
+// 16 column groups of 8 (16-B loads) x 16 row lanes, four rows in flight per lane.
 __global__ __launch_bounds__(256) void xattn_colsum_kernel(const bf16_t* dS, float* out, int I, int R, float scale) {
-    __shared__ float part[4][64];
-    const int b = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (n < R) {
-        const bf16_t* p = dS + (int64_t)b * I * R + n;
-        for (int i = sub; i < I; i += 4) acc += bf2f(p[(int64_t)i * R]);
+    __shared__ float part[16][16][9];
+    const int b = blockIdx.y, cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n0 = blockIdx.x * 128 + cg * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n0 < R) {
+        const bf16_t* p = dS + (int64_t)b * I * R + n0;
+        auto add = [&](const u32x4 v) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(v[q] << 16); acc[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u); }
+        };
+        int i = rl;
+        for (; i + 48 < I; i += 64) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(p + (int64_t)(i + 16 * u) * R);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u]);
+        }
+        for (; i < I; i += 16) add(*(const u32x4*)(p + (int64_t)i * R));
     }
-    part[sub][threadIdx.x & 63] = acc;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) part[rl][cg][t] = acc[t];
     __syncthreads();
-    if (sub == 0 && n < R) out[(int64_t)b * R + n] = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (rl == 0 && n0 < R) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_ += part[r][cg][t];
+            out[(int64_t)b * R + n0 + t] = scale * s_;
+        }
+    }
 }
 
 // out[h dh + d] += sum_m w[(m / T) R + (m % T) w_t + h w_h] * X[m][h dh + d]      (bias gradients of the absorbed projections;
@@ -1136,7 +1159,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
             a.residual = (const bf16_t*)d.ws_ds;
             XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
         }
-        hipLaunchKernelGGL(xattn_colsum_kernel, dim3((R + 63) / 64, B), dim3(256), 0, s, dS, dcb, I, R, scale);
+        hipLaunchKernelGGL(xattn_colsum_kernel, dim3((R + 127) / 128, B), dim3(256), 0, s, dS, dcb, I, R, scale);
         XCHK(hip_launch_status());
         {   // per head: dk_h = scale dK'_h Wq_h^T + dcb bq_h ; dv_h = dV'_h Wo[:, h]
             XgArgs a{};
