@@ -306,11 +306,8 @@ int m3ae_mim_loss_bwd(const void* x, const float* target, const float* mask, con
  * contract -- the product path (m3ae_amd/) never calls this; launch policy that callers need is per call
  * (m3ae_gemm_desc.launch_flags).
  * key 0: NT GEMM kernel (-1 = auto by shape; 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its
- *        persistent form, 9 = dual kernel: 128x256 tiles, two workgroups per CU);
+ *        persistent form);
  * key 1: TN (wgrad) kernel (-1 = auto by shape; 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong);
- * key 4: dual NT kernel, start-up delay of a CU's second workgroup in 100-MHz ticks (-1 = from K);
- * key 5: dual NT kernel, 1 = every workgroup overwrites 28 B of its tile with (HW_ID, XCC_ID, start, main-loop end,
- *        epilogue end, launch index, shader clocks) -- DIAGNOSTIC, corrupts C (tools/nt_trace.py);
  * key 6: 1 (default) = the auto path may use the persistent NT kernel; 0 = never (data-parallel runs: RCCL kernels
  *        hold CUs concurrently, see gemm_mfma.hip). */
 int m3ae_set_tuning(int key, int value);

@@ -49,8 +49,6 @@ struct MfmaArgs {
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
     int col_group;      // ping-pong NT kernels: column tiles per group of the tile order (nt_tile_coords)
     int no_persist;     // desc.launch_flags & M3AE_GEMM_NO_PERSISTENT
-    int trace;          // dual NT kernel: overwrite 28 B of every tile's first row with (hw_id, xcc_id, t0, t1, t2, block, clocks)
-    int stagger_ticks;  // dual NT kernel: start-up delay of the second workgroup of every CU (100-MHz ticks)
 };
 
 // Tile order inside the (XCD-contiguous) id range: column tiles in groups of GC, row-major inside a group.  An XCD then
@@ -491,12 +489,8 @@ static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIA
 // one-tile-per-workgroup launch just runs on the CUs that are free
 static int g_nt_persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
 static int g_nt_col_group = 0;   // 0: by shape (launch_nt)
-static int g_nt_trace = 0;
-static int g_stagger_ticks = -1;   // -1: from K (launch_nt_dual)
 extern "C" int m3ae_set_tuning(int key, int value) {
     if (key == 0) { g_nt_variant = value; return 0; }
-    if (key == 4) { g_stagger_ticks = value; return 0; }
-    if (key == 5) { g_nt_trace = value; return 0; }
     if (key == 6) { g_nt_persist = value; return 0; }
     if (key == 7) { g_nt_col_group = value; return 0; }
     if (key == 1) { g_tn_variant = value; return 0; }
@@ -822,162 +816,18 @@ static int launch_nt_pp_persistent(const MfmaArgs& a, hipStream_t s) {
     return hip_launch_status();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// NT "dual" kernel: 128 x 256 tile, 4 waves (1 x 4, 128 x 64 each, one per SIMD), 32-deep chunks in a 3-slot LDS ring
-// (72 KiB), TWO workgroups per CU.  Measured on the ping-pong kernel (r01 probes: stores removed / main loop cut to 3
-// chunks): at K = 768 a tile spends 30-45 % of its time in its epilogue (GELU + derivative: VALU; derivative / residual
-// classes: the operand fetch; every class: the LDS transposes) with the MFMA pipe idle, because all 8 waves of the CU's
-// only workgroup are in the epilogue together.  Here the second workgroup's main loop runs under the first one's
-// epilogue and prologue.  For that a single wave must keep the MFMA pipe busy by itself, so the fragments are
-// software-pipelined in registers: a chunk is two MFMA clusters (output rows 0-63 / 64-127); the A fragments of the
-// second cluster are read during the first, the next chunk's B and first-half A fragments during the second (two
-// register sets, loop unrolled by two), and the only barrier of a chunk sits between the clusters.
-//   mid-chunk t:  lgkmcnt(0) (this wave's reads of slot t are retired)  ->  vmcnt (its pieces of chunk t + 1 landed)
-//                 ->  s_barrier  ->  DMA of chunk t + 3 into slot t % 3  ->  fragment reads of chunk t + 1.
-// Accumulation order = gemm_nt_pp_kernel's (bit-identical results).  The workgroups that start as the second resident
-// of a CU (launch index in [CUs, 2 CUs)) sleep for about half a main loop first, otherwise the pair would run its
-// epilogues together; the offset then persists from tile to tile (the one in its epilogue leaves the pipe to the other).
-// ---------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dual_kernel(MfmaArgs a, unsigned second_lo, unsigned second_hi) {
-    constexpr int CK = 32, NW = 4, A_BYTES = 128 * CK * 2, SLOT = A_BYTES + 256 * CK * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned tiles_n = (unsigned)((a.N + 255) / 256);
-    unsigned tm, tn;
-    nt_tile_coords(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / tiles_n, tiles_n, tm, tn);
-    const int64_t m0 = (int64_t)tm * 128, n0 = (int64_t)tn * 256;
-    if (a.stagger_ticks > 0 && blockIdx.x < second_hi) {
-        // first generation: the workgroup whose wave 0 sits in an odd wave slot of its SIMD is the CU's second resident
-        if (tid == 0) *(volatile int*)smem = (int)(__builtin_amdgcn_s_getreg(0x1804) & 1u);   // HW_ID.wave_id[3:0]
-        __syncthreads();
-        const int second = *(volatile int*)smem;
-        __syncthreads();
-        if (second) {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    const uint32_t tr0 = a.trace ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
-    const uint32_t tc0 = a.trace ? (uint32_t)__builtin_readcyclecounter() : 0u;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nc = (int)(a.K / CK);   // even, >= 4 (host check)
-    auto stage = [&](int c) {
-        char* sl = smem + (c % 3) * SLOT;
-        nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wc, lane);
-        nt_stage<CK, 4, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wc, lane);
-    };
-    stage(0); stage(1); stage(2);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    PP_FENCE();
-    __builtin_amdgcn_s_barrier();
-    PP_FENCE();
-
-    const int frow = lane & 15, fchunk = lane >> 4;
-    s16x8 bf0[4], al0[4], bf1[4], al1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bf0[j] = nt_frag<CK>(smem + A_BYTES, wc * 64 + j * 16 + frow, fchunk);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) al0[i] = nt_frag<CK>(smem, i * 16 + frow, fchunk);
-
-    // one chunk: fragments (bc, lc) are in registers; fills (bn, ln) with chunk t + 1's
-#define DUAL_CHUNK(t, bc, lc, bn, ln)                                                                                   \
-    {                                                                                                                   \
-        const char* At = smem + ((t) % 3) * SLOT;                                                                       \
-        s16x8 ah[4];                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bc[j]),                \
-                                                                    __builtin_bit_cast(bf16x8_t, lc[i]), acc[i][j], 0, 0, 0); \
-        PP_FENCE();                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = nt_frag<CK>(At, 64 + i * 16 + frow, fchunk);              \
-        PP_FENCE();                                                                                                     \
-        _Pragma("unroll") for (int i = 2; i < 4; ++i)                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bc[j]),                \
-                                                                    __builtin_bit_cast(bf16x8_t, lc[i]), acc[i][j], 0, 0, 0); \
-        PP_FENCE();                                                                                                     \
-        /* the builtin (not inline asm) so that the compiler's own wait-count pass knows the LDS queue is drained */     \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                     /* lgkmcnt(0), on every path */                         \
-        if ((t) + 2 < nc) __builtin_amdgcn_s_waitcnt(0x0f76);   /* vmcnt(6) */                                          \
-        else __builtin_amdgcn_s_waitcnt(0x0f70);                /* vmcnt(0) */                                          \
-        PP_FENCE();                                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                                   \
-        PP_FENCE();                                                                                                     \
-        if ((t) + 3 < nc) stage((t) + 3);                                                                               \
-        {   /* past the last chunk this reads a free slot of the ring: the values are never used */                     \
-            const char* An = smem + (((t) + 1) % 3) * SLOT;                                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) bn[j] = nt_frag<CK>(An + A_BYTES, wc * 64 + j * 16 + frow, fchunk); \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) ln[i] = nt_frag<CK>(An, i * 16 + frow, fchunk);               \
-        }                                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);   /* keep the reads ahead of the cluster that hides them */                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bc[j]),            \
-                                                                        __builtin_bit_cast(bf16x8_t, ah[i]), acc[4 + i][j], 0, 0, 0); \
-        PP_FENCE();                                                                                                     \
-    }
-    for (int t = 0; t < nc; t += 2) {
-        DUAL_CHUNK(t, bf0, al0, bf1, al1)
-        DUAL_CHUNK(t + 1, bf1, al1, bf0, al0)
-    }
-#undef DUAL_CHUNK
-    // the last chunk's mid barrier came after every wave's last fragment read and no DMA is outstanding: the ring is free
-    const uint32_t tr1 = a.trace ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
-    if (a.c_f32) epilogue_rows<float, EPI, 8>(a, smem, wc, lane, m0, n0 + wc * 64, acc);
-    else epilogue_rows<bf16_t, EPI, 8>(a, smem, wc, lane, m0, n0 + wc * 64, acc);
-    if (a.trace && tid == 0 && !a.c_f32) {   // diagnostic (tools/nt_trace.py): placement and timeline of this tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t* o = (uint32_t*)((bf16_t*)a.C + m0 * a.ldc + n0);
-        o[0] = __builtin_amdgcn_s_getreg(0xf804);            // HW_ID (wave, simd, cu, sh, se ...)
-        o[1] = __builtin_amdgcn_s_getreg(0xf814);            // XCC_ID
-        o[2] = tr0; o[3] = tr1; o[4] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[5] = blockIdx.x;
-        o[6] = (uint32_t)__builtin_readcyclecounter() - tc0;   // shader clocks of the whole tile (s_memtime)
-    }
-}
-
-template <int EPI>
-static int launch_nt_dual(const MfmaArgs& a0, hipStream_t s) {
-    constexpr int lds = 3 * (128 + 256) * 32 * 2;   // 72 KiB ring; the epilogue slabs (4 x 8704 B) reuse it
-    static bool attr_set = false;
-    static int cus = 256;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dual_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        attr_set = true;
-    }
-    MfmaArgs a = a0;
-    // about half a main loop (measured ~0.5 us per chunk with both workgroups of the CU in their main loops)
-    a.trace = g_nt_trace;
-    a.stagger_ticks = g_stagger_ticks >= 0 ? g_stagger_ticks : (int)(a.K / 32) * 25;
-    const int64_t tiles = cdiv(a.M, 128) * cdiv(a.N, 256);
-    g_last_path = "mfma_nt_dual";
-    hipLaunchKernelGGL((gemm_nt_dual_kernel<EPI>), dim3((unsigned)tiles), dim3(256), lds, s, a, (unsigned)cus,
-                       (unsigned)(2 * cus));
-    return hip_launch_status();
-}
-
 // variants (m3ae_set_tuning key 0):
 //   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU (small / few-tile shapes)
 //   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU (the ping-pong kernel's
 //      bit-exact reference in tools/gemm_race.py)
 //   7: 256x256 tile, 32-deep chunks in a 4-slot ring, 8 waves in two staggered rows (ping-pong, gemm_nt_pp_kernel)
-//   9: 128x256 tile, 4 waves, two workgroups per CU, fragments software-pipelined in registers (gemm_nt_dual_kernel)
-// Tilings tried and dropped (measured slower on every shape of the path, r01 logs): 256x128 with BK 64 / 3 stages,
+//   8: the persistent form of 7 (static tile lists, one workgroup per CU; >= 512 tiles)
+// Tilings tried and dropped (measured slower on every shape of the path, r01 logs): a 128x256 "dual" kernel (4 waves, two
+// workgroups per CU so that one's main loop runs under the other's epilogue; bit-identical, 3-9 % slower, removed in r02);
+// 256x128 with BK 64 / 3 stages,
 // 256x128 with BK 32 / 2 and 3 stages, 256x256 with BK 32 / 4 stages (single barrier), 128x128 with BK 32;
-// 256x256 with FOUR waves of 128x128 (256 accumulators pinned to AGPRs through asm constraints, one wave per SIMD, the
-// dual kernel's software pipeline, 33 % fewer LDS fragment bytes per MFMA): bit-identical, 1143 vs 1281 TF/s at 8192^3
+// 256x256 with FOUR waves of 128x128 (256 accumulators pinned to AGPRs through asm constraints, one wave per SIMD, fragments
+// software-pipelined in registers, 33 % fewer LDS fragment bytes per MFMA): bit-identical, 1143 vs 1281 TF/s at 8192^3
 // and 12-25 % slower on the path's shapes (profiles/r01_nt_w4_probe.log) -- one wave per SIMD does not keep the MFMA
 // pipe as busy as the two staggered wave rows do.
 template <int EPI>
@@ -1003,9 +853,6 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         return launch_nt_pp_persistent<EPI>(a, s);                                    // persistent ping-pong
     if (g_nt_variant == 8 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);
     if (g_nt_variant == 4 && a.M > 128 && a.N > 128) return launch_nt_t<256, 256, 64, 2, 128, EPI>(a, s);
-    if (g_nt_variant == 9 && a.rows_epi && a.K % 64 == 0 && a.K >= 128 && a.M > 128 && a.N > 128)
-        return launch_nt_dual<EPI>(a, s);
-    if (g_nt_variant == 9 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);
     return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
 }
 
@@ -1047,6 +894,8 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
 // 4-slot ring; two phases per chunk (output rows 0-63 / 64-127 of the wave), the two wave rows staggered by one
 // barrier; B(c+3) / A(c+3) issued in phases 2c / 2c+1, counted vmcnt(8) in the odd phase.  Split over the reduction
 // with fp32 atomics; the bias gradient rides on a ones-fragment MFMA in the first column tile's waves.
+// Ring depth: a 5-slot ring (160 KiB, three chunks in flight behind the one awaited) measured the same as 4 slots on every
+// wgrad shape of the step (r02, profiles/r02_tn_ring_depth.log): the kernel is not waiting on load latency.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;

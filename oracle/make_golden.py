@@ -238,8 +238,11 @@ def run_pretrain():
     print("[pretrain] mlm", res["mlm_loss"], "mim", res["mim_loss"], "itm", res["itm_loss"])
 
 
-def run_t5():
-    """configs[2] path on a tiny model: the reference's T5VQA_MMEncoderInput (m3ae_t5_mm_encoder_input.py) with
+def run_t5(tag="tiny_t5", layers=2, VOC=1100):
+    """configs[2] path on a tiny model (tag "tiny_t5": 2 + 2 T5 layers, vocabulary 1100) and on the reference's full head
+    architecture (tag "t5small_full": t5-small as the reference hard-codes it, m3ae_t5_mm_encoder_input.py:26-27 -- 6 + 6
+    layers, 8 heads, d_ff 2048, vocabulary 32128 -- behind the tiny M3AE; logits stored at every 64th column plus their
+    row-wise logsumexp): the reference's T5VQA_MMEncoderInput (m3ae_t5_mm_encoder_input.py) with
     random-init HF T5 (d_model 512 is hard-wired in the reference's prepare_inputs), 2+2 layers, deterministic
     weights, a fixed (instead of per-call random) CLS projection, unfreeze_top_layers(4, 4) as main_t5_m3ae.py:30."""
     rs.install()
@@ -248,8 +251,6 @@ def run_t5():
     from transformers import T5Config, T5ForConditionalGeneration
     import m3ae.modules.m3ae_t5_mm_encoder_input as tm
     import m3ae.modules.m3ae_t5_utils as tu
-
-    VOC = 1100
 
     class Tok:
         pad_token_id, eos_token_id = 0, 1
@@ -272,7 +273,7 @@ def run_t5():
     class T5Stub:
         @staticmethod
         def from_pretrained(*a, **k):
-            cfg = T5Config(vocab_size=VOC, d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2,
+            cfg = T5Config(vocab_size=VOC, d_model=512, d_kv=64, d_ff=2048, num_layers=layers, num_decoder_layers=layers,
                            num_heads=8, dropout_rate=0.1, feed_forward_proj="relu", tie_word_embeddings=True,
                            decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
             cfg._attn_implementation = "eager"
@@ -313,8 +314,13 @@ def run_t5():
         lab = Tok()([a[0] for a in batch["vqa_answer"]]).input_ids
         o = m.t5(encoder_outputs=enc, labels=lab, return_dict=True)
     assert abs(o.loss.item() - loss.item()) < 1e-5
-    res = {"loss": np.float64(loss.item()), "logits": o.logits.numpy(), "labels": lab.numpy(),
+    res = {"loss": np.float64(loss.item()), "labels": lab.numpy(),
            "inputs_embeds_head": inp["inputs_embeds"][:, :4].numpy(), "enc_out": enc.last_hidden_state[:, :8].numpy()}
+    if VOC <= 4096:
+        res["logits"] = o.logits.numpy()
+    else:
+        res["logits_stride64"] = o.logits[:, :, ::64].numpy()
+        res["logits_lse"] = torch.logsumexp(o.logits.double(), -1).numpy()
     names, gn = [], []
     for n, p in m.named_parameters():
         if p.grad is not None:
@@ -322,8 +328,8 @@ def run_t5():
             gn.append(p.grad.double().norm().item())
     res["grad_names"], res["grad_norm"] = np.array(names), np.array(gn)
     res["trainable_names"] = np.array([n for n, p in m.named_parameters() if p.requires_grad])
-    np.savez_compressed(os.path.join(GOLD, "tiny_t5.npz"), **res)
-    print("[t5] loss", loss.item(), "trainable", len(res["trainable_names"]), "with grad", len(names))
+    np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **res)
+    print(f"[{tag}] loss", loss.item(), "trainable", len(res["trainable_names"]), "with grad", len(names))
 
 
 DEC_M3AE = dict(image_size=64, hidden_size=768, num_heads=12, num_top_layer=1, input_image_embed_size=128,
@@ -477,7 +483,7 @@ def run_mlm_collate():
 
 
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "decoder", "t5gen", "mlm"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "t5small", "decoder", "t5gen", "mlm"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -485,6 +491,8 @@ def main():
         run_pretrain()
     if "t5" in what:
         run_t5()
+    if "t5small" in what:
+        run_t5("t5small_full", layers=6, VOC=32128)
     if "decoder" in what:
         run_decoder()
     if "t5gen" in what:

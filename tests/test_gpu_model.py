@@ -240,9 +240,9 @@ def test_full_size_bf16_step_and_optimizer():
 T5_DIMS = dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2, num_decoder_layers=2, num_heads=8)
 
 
-def _build_t5(mode, dtype):
+def _build_t5(mode, dtype, vocab=1100, dims=None):
     from m3ae_amd.modules import T5VQA_MMEncoderInput
-    m = T5VQA_MMEncoderInput(tiny_config(compute_dtype=mode), t5_vocab=1100, t5_dims=T5_DIMS)
+    m = T5VQA_MMEncoderInput(tiny_config(compute_dtype=mode), t5_vocab=vocab, t5_dims=dims or T5_DIMS)
     m.unfreeze_top_layers(4, 4)  # main_t5_m3ae.py:30
     synth.fill_deterministic(m)
     m.finalize("cuda", dtype)
@@ -281,6 +281,44 @@ def test_tiny_t5_generative_head_against_reference_fixture(mode):
         assert abs(mine - r) <= tol * r + 1e-3 * tol * ref_total, (n, mine, r)
     m.store.adamw_step(max_steps=100, lr_factor=1.0)
     assert torch.isfinite(m.store.flat).all()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_full_t5_small_generative_head_against_reference_fixture(mode):
+    """The head architecture the reference hard-codes (t5-small at full depth: 6 + 6 layers, 8 heads, d_ff 2048, vocabulary
+    32128; m3ae_t5_mm_encoder_input.py:26-27), forward + backward, against the fixture captured from the reference
+    (oracle/make_golden.py t5small): loss, logits at every 64th column, their row-wise logsumexp, all 72 gradient norms."""
+    dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    m = _build_t5(mode, dtype, vocab=32128, dims=dict(T5_DIMS, num_layers=6, num_decoder_layers=6))
+    g = load_golden("t5small_full.npz")
+    b = to_dev(tiny_batch())
+    b["t5_labels"] = torch.from_numpy(g["labels"]).cuda()
+    m.store.zero_grad()
+    m.current_tasks = ["vqa"]
+    out = m(b)
+    loss = out["vqa_loss"]
+    logits = out["vqa_logits"].detach().float()
+    lse = torch.logsumexp(logits.double(), -1).cpu().numpy()
+    sub = logits[:, :, ::64].cpu().numpy()
+    if mode == "fp32":
+        np.testing.assert_allclose(sub, g["logits_stride64"], rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(lse, g["logits_lse"], rtol=1e-5)
+        assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    else:
+        assert np.abs(sub - g["logits_stride64"]).max() < 0.05 * max(1.0, np.abs(g["logits_stride64"]).max())
+        np.testing.assert_allclose(lse, g["logits_lse"], rtol=5e-3)
+        assert abs(loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
+    m.training_step(b)["loss"].backward()
+    params = dict(m.named_parameters())
+    tol = 2e-3 if mode == "fp32" else 8e-2
+    ref_total = float(np.sqrt((g["grad_norm"] ** 2).sum()))
+    assert len(g["grad_names"]) == 72
+    # noise floor: with these weights the attention is nearly uniform and the q / k gradients are ~3e-4 of the total norm;
+    # bf16 rounding of the activations alone is worth 1e-3 of it
+    floor = (2e-6 if mode == "fp32" else 1e-3) * ref_total
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = params[n].grad.double().norm().item()
+        assert abs(mine - r) <= tol * r + floor, (n, mine, r)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

@@ -52,7 +52,7 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
         assert ops.last_gemm_path() == expect
 
 
-@pytest.mark.parametrize("variant", [0, 4, 7, 9])
+@pytest.mark.parametrize("variant", [0, 4, 7])
 def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
     from m3ae_amd import _lib
@@ -61,7 +61,7 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
                     (2308, 2304, 768)]:
         x, w = rnd(M, K, dtype=torch.bfloat16, seed=5), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=6)
         y1, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32)
-        assert ops.last_gemm_path() in ("mfma_nt", "mfma_nt_pp", "mfma_nt_dual")
+        assert ops.last_gemm_path() in ("mfma_nt", "mfma_nt_pp")
         y2, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32, force_generic=True)
         assert ops.last_gemm_path() == "generic"
         close(y1, y2, 1e-5, 1e-5, msg=f"{M}x{N}x{K}")
@@ -629,8 +629,8 @@ def test_gemm_epilogue_dropout_after_activation_and_in_dgrad(dtype):
 
 @pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul"])
 def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
-    """Every NT kernel the auto path or a tuning key can select -- 256x256 2-stage (4), ping-pong (7), its persistent form
-    (8, >= 512 tiles), the dual kernel (9: 128x256 tiles, two workgroups per CU) -- accumulates in the same order: on the
+    """Every NT kernel the auto path or a tuning key can select for large shapes -- 256x256 2-stage (4), ping-pong (7), its
+    persistent form (8, >= 512 tiles) -- accumulates in the same order: on the
     path's own large shapes and epilogue classes the bf16 outputs are identical, ragged row tail included."""
     from m3ae_amd import _lib
     L = _lib.lib()
@@ -641,7 +641,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     aux = rnd(M, N, dtype=torch.bfloat16, seed=24)
     outs = {}
     try:
-        for v in (4, 7, 8, 9):
+        for v in (4, 7, 8):
             L.m3ae_set_tuning(0, v)
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             extra = None
@@ -655,8 +655,8 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
             else:
                 ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_MULAUX)
             outs[v] = (y, extra, ops.last_gemm_path())
-        assert outs[9][2] == "mfma_nt_dual" and outs[8][2] == "mfma_nt_pp"
-        for v in (7, 8, 9):
+        assert outs[8][2] == "mfma_nt_pp"
+        for v in (7, 8):
             assert torch.equal(outs[v][0].view(torch.int16), outs[4][0].view(torch.int16)), (kind, v)
             if outs[4][1] is not None:
                 assert torch.equal(outs[v][1].view(torch.int16), outs[4][1].view(torch.int16)), (kind, v, "derivative")

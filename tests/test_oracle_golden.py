@@ -134,11 +134,11 @@ def test_large_tower_dims_reduced_depth_matches_reference():
     _grad_check(sd, g, rtol=1e-3)
 
 
-def _t5_sd():
+def _t5_sd(vocab=1100, layers=2):
     from m3ae_amd.modules import T5VQA_MMEncoderInput
     with torch.device("meta"):
-        m = T5VQA_MMEncoderInput(tiny_config(), t5_vocab=1100, t5_dims=dict(d_model=512, d_kv=64, d_ff=2048, num_layers=2,
-                                                                         num_decoder_layers=2, num_heads=8))
+        m = T5VQA_MMEncoderInput(tiny_config(), t5_vocab=vocab, t5_dims=dict(d_model=512, d_kv=64, d_ff=2048, num_layers=layers,
+                                                                          num_decoder_layers=layers, num_heads=8))
     sd = {k: torch.empty(v.shape, dtype=torch.float32) for k, v in m.state_dict().items()}
     from m3ae_amd import synth
     synth.fill_deterministic(sd)
@@ -163,6 +163,32 @@ def test_tiny_t5_head_matches_reference():
     np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-5)
     assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
     loss.backward()
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = sd[n].grad.double().norm().item()
+        assert abs(mine - r) <= 1e-3 * r + 1e-9, (n, mine, r)
+
+
+def test_full_t5_small_head_matches_reference():
+    """The head architecture the reference hard-codes (t5-small: 6 + 6 layers, 8 heads, d_ff 2048, vocabulary 32128;
+    m3ae_t5_mm_encoder_input.py:26-27) at full depth behind the tiny M3AE: loss, logits (every 64th column + row-wise
+    logsumexp) and every gradient norm against the fixture captured from the reference."""
+    torch.set_num_threads(8)
+    cfg = tiny_config()
+    sd = _t5_sd(32128, 6)
+    g = load_golden("t5small_full.npz")
+    for t in sd.values():
+        t.requires_grad_(True)
+    m3 = {k[5:]: v for k, v in sd.items() if k.startswith("m3ae.")}
+    b = tiny_batch()
+    with torch.no_grad():
+        cls = O.infer(m3, oracle_cfg(cfg), b["image"][0], b["text_ids"], b["text_masks"])["multi_modal_cls_feats"]
+    x = O.t5_head_inputs(sd, cls, torch.tensor([822, 10]), sd["cls_projection.weight"], sd["cls_projection.bias"])
+    loss, logits = O.t5_loss(sd, x, torch.from_numpy(g["labels"]), 8)
+    np.testing.assert_allclose(logits[:, :, ::64].detach().numpy(), g["logits_stride64"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(torch.logsumexp(logits.double(), -1).detach().numpy(), g["logits_lse"], rtol=1e-6)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    assert len(g["grad_names"]) == 72
     for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
         mine = sd[n].grad.double().norm().item()
         assert abs(mine - r) <= 1e-3 * r + 1e-9, (n, mine, r)
