@@ -284,7 +284,9 @@ def main():
                     tj = json.load(f)
                 if tj.get("per_gpu_batch") == B and tj.get("head") == args.head:
                     roofline["traffic"] = tj["gemm_nt_pp_kernel"]["bytes_per_launch"]
-                    roofline["traffic_source"] = ("committed profile " + tp[len(ROOT) + 1:] + " @" + profile_commit(tp) +
+                    # the snapshot on a GPU box has no .git: the profile carries the commit of the code it measured
+                    roofline["traffic_source"] = ("committed profile " + tp[len(ROOT) + 1:] + ", taken at commit " +
+                                                  str(tj.get("commit", profile_commit(tp))) +
                                                   " (NOT measured in this run; HEAD is " + profile_commit(None) + ")")
                     roofline["traffic_unit"] = "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; " + tp[len(ROOT) + 1:] + ")"
                     # MFMA-pipe busy fraction and effective clock of the same kernel from the committed counter pass
@@ -292,10 +294,12 @@ def main():
                     mp = tp.replace("_pmc_traffic.json", "_pmc_mfma.json")
                     if os.path.exists(mp):
                         with open(mp) as f:
-                            mk = [v for k, v in json.load(f)["kernels"].items() if k.startswith("gemm_nt_pp")]
+                            mj = json.load(f)
+                        mk = [v for k, v in mj["kernels"].items() if k.startswith("gemm_nt_pp")]
                         ms_ = sum(v["total_ms"] for v in mk)
                         if ms_ > 0:
-                            roofline["pmc_source"] = ("committed profile " + mp[len(ROOT) + 1:] + " @" + profile_commit(mp) +
+                            roofline["pmc_source"] = ("committed profile " + mp[len(ROOT) + 1:] + ", taken at commit " +
+                                                      str(mj.get("commit", profile_commit(mp))) +
                                                       " (NOT measured in this run)")
                             roofline["mfma_busy_pmc"] = round(sum(v["mfma_util"] * v["total_ms"] for v in mk) / ms_, 3)
                             roofline["clock_mhz_pmc"] = round(sum(v["clock_mhz"] * v["total_ms"] for v in mk) / ms_)
