@@ -15,10 +15,13 @@ The reference's arithmetic is kept as it is, quirks included (each is pinned by 
   * loss = CrossEntropy(mean over non-[PAD] golden tokens) (:226,:366-368 reduce to exactly that);
   * decoder input = tokens[:, :-1] with [SEP] -> [PAD], golden = tokens[:, 1:] (:344-351,:362).
 
-Arithmetic: the head has 8 heads of 96 channels (768 / 8); the MFMA attention kernels are specialised for 64-wide heads,
-so the head runs in fp32 on the library's generic kernels (fp32 master weights, materialised-softmax attention) in
-both modes (train() mode applies the reference's dropout sites with the library's counter-hash masks); the frozen M3AE below it runs in the configured mode (bf16 MFMA in perf mode).  T <= 12 tokens against
-2 (CLS) or 2 + 577 + 32 encoder tokens: the head is < 3 % of the step's FLOPs except for the vocabulary projection.
+Arithmetic: the head follows the configured mode like the M3AE below it.  Parity mode: fp32 on the library's generic
+kernels (fp32 master weights, materialised-softmax attention).  Perf mode: bf16 activations, every Linear (in / out
+projections, FFN, the vocabulary projection through `ops.vocab_linear`) on the bf16 MFMA GEMMs against the weight shadows;
+the head has 8 heads of 96 channels (768 / 8) and the MFMA attention kernels are specialised for 64-wide heads, so its
+two attentions run the fp32 materialised-softmax kernels on fp32 copies of the bf16 projections (`ops.attn_forward`:
+T <= 12 tokens against 2 (CLS) or 2 + 577 + 32 encoder tokens -- a few % of the head's work).  train() mode applies the
+reference's dropout sites with the library's counter-hash masks.
 Tokenisation happens outside (`batch["decoder_tokens"]`: int64 [B, T] = [CLS] answer [SEP] [PAD]...) or through a
 `tokenizer` callable; string metrics (ROUGE / BLEU / exact match) stay out of scope.
 """
@@ -138,7 +141,7 @@ class _DecoderEmbedFn(torch.autograd.Function):
     """2 * embedding[ids] + pe (m3ae_decoder.py:125-127), gradient 2 * d_out scatter-added into the table."""
 
     @staticmethod
-    def forward(ctx, ids, weight, pe_rows):
+    def forward(ctx, ids, weight, pe_rows, out_dtype=torch.float32):
         n, D = ids.numel(), weight.shape[1]
         L = ops._lib.lib()
         e = torch.empty((n, D), dtype=weight.dtype, device=weight.device)
@@ -149,20 +152,20 @@ class _DecoderEmbedFn(torch.autograd.Function):
         ops.check(L.m3ae_add(ops._p(out), ops._p(pe_rows), ops._p(out), e.numel(), ops._dt(e), ops._stream()), "m3ae_add")
         ctx.save_for_backward(ids)
         ctx.weight = weight
-        return out
+        return out.to(out_dtype)   # gathered and doubled from the fp32 master rows, rounded once
 
     @staticmethod
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         w = ctx.weight
         if w.requires_grad:
-            d = dout.contiguous()
+            d = dout.float().contiguous()
             d2 = torch.empty_like(d)
             ops.check(ops._lib.lib().m3ae_add(ops._p(d), ops._p(d), ops._p(d2), d.numel(), ops._dt(d), ops._stream()),
                       "m3ae_add")
-            ops._grad_buf(w).index_add_(0, ids, d2.float())
+            ops._grad_buf(w).index_add_(0, ids, d2)
             ops._done(w)
-        return None, None, None
+        return None, None, None, None
 
 
 class Decoder(nn.Module):
@@ -176,23 +179,31 @@ class Decoder(nn.Module):
         self.positional_encoding = PositionalEncoding(d_model)
         self.final_linear = nn.Linear(d_model, target_vocab_size)
         self.p_drop = dropout   # nn.Dropout on the (doubled) embedding (:128)
+        self.head_dtype = torch.float32   # DecoderModel.finalize: the configured compute dtype
 
     def weight_units(self):
-        return []  # the head runs in fp32 on the master weights: no bf16 transposed copies
+        """GEMM weights that need a transposed bf16 copy for dgrad (perf mode): the live layer's and the vocabulary
+        projection; none in parity mode (the fp32 kernels read the master weights through strides)."""
+        if self.head_dtype != torch.bfloat16:
+            return []
+        l = self.dec_layers[self.num_layers - 1]
+        return [l.mha1.in_proj_weight, l.mha1.out_proj.weight, l.mha2.in_proj_weight, l.mha2.out_proj.weight,
+                l.ffn[0].weight, l.ffn[2].weight, self.final_linear.weight]
 
     def forward(self, padded_targets, padding_mask, cross_attn_feats):
-        """padded_targets int64 [B, T]; padding_mask bool [B, T] (True = token) or None; features fp32 [B, Le, D]."""
+        """padded_targets int64 [B, T]; padding_mask bool [B, T] (True = token) or None; features [B, Le, D]."""
         B, T = padded_targets.shape
         D = self.target_embedding.weight.shape[1]
         pe_rows = self.positional_encoding.pe[0, :T].to(torch.float32).repeat(B, 1).contiguous()
-        t = _DecoderEmbedFn.apply(padded_targets.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows)
+        t = _DecoderEmbedFn.apply(padded_targets.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows,
+                                  self.head_dtype)
         t = ops.dropout(t.view(B, T, D), self.p_drop, self.training)
         key_mask = None
         if padding_mask is not None:
             key_mask = torch.where(padding_mask, 0.0, NEG).to(torch.float32).contiguous()
         # the reference runs all layers on `t` and keeps the last result (:131-134): run the last one only
-        x = self.dec_layers[self.num_layers - 1](t, cross_attn_feats, key_mask)
-        return ops.linear(x, self.final_linear.weight, self.final_linear.bias)
+        x = self.dec_layers[self.num_layers - 1](t, cross_attn_feats.to(self.head_dtype), key_mask)
+        return ops.vocab_linear(x, self.final_linear.weight, self.final_linear.bias)
 
     @torch.no_grad()
     def step_logits(self, last_ids, pos, enc_kv, cache):
@@ -200,9 +211,10 @@ class Decoder(nn.Module):
         come from `cache`, the encoder side from `enc_kv`; equal to forward(prefix)[:, -1] (eval mode)."""
         B = last_ids.shape[0]
         pe_rows = self.positional_encoding.pe[0, pos:pos + 1].to(torch.float32).repeat(B, 1).contiguous()
-        t = _DecoderEmbedFn.apply(last_ids.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows)
+        t = _DecoderEmbedFn.apply(last_ids.reshape(-1).contiguous(), self.target_embedding.weight, pe_rows,
+                                  self.head_dtype)
         x = self.dec_layers[self.num_layers - 1].step(t.view(B, 1, -1), enc_kv, cache, pos)
-        return ops.linear(x, self.final_linear.weight, self.final_linear.bias)[:, -1]
+        return ops.vocab_linear(x, self.final_linear.weight, self.final_linear.bias)[:, -1]
 
     @torch.no_grad()
     def search_path(self, cross_attn_feats, cls_id=101, sep_id=102, eos_id=None, pad_id=0, use_cache=True):
@@ -215,8 +227,8 @@ class Decoder(nn.Module):
         layer = self.dec_layers[self.num_layers - 1]
         if use_cache:
             D = self.target_embedding.weight.shape[1]
-            enc_kv = layer.cross_kv(cross_attn_feats)
-            cache = torch.empty((B, self.max_len, 2 * D), dtype=torch.float32, device=dev)
+            enc_kv = layer.cross_kv(cross_attn_feats.to(self.head_dtype))
+            cache = torch.empty((B, self.max_len, 2 * D), dtype=self.head_dtype, device=dev)
         for step in range(self.max_len):
             if use_cache:
                 nxt = self.step_logits(seq[:, -1:], step, enc_kv, cache).argmax(dim=-1)
@@ -264,7 +276,7 @@ class DecoderModel(_Base):
         self.store = None
 
     def weight_units(self):
-        return self.m3ae.weight_units()
+        return list(self.m3ae.weight_units()) + self.decoder.weight_units()
 
     def finalize(self, device="cuda", compute_dtype=None):
         cfg = self.m3ae.hparams.config
@@ -275,12 +287,10 @@ class DecoderModel(_Base):
         # layers 0 .. n-2 never receive a gradient in the reference (torch's AdamW skips them: no update, no weight
         # decay): keep them out of the optimizer / all-reduce buffers
         dead = tuple(f"decoder.dec_layers.{i}." for i in range(self.decoder.num_layers - 1))
+        self.decoder.head_dtype = self.m3ae._dtype   # before the store asks for the weight units
         self.store = ParamStore(self, cfg, device, self.m3ae._dtype, self.weight_units, frozen=dead,
                                 group_fn=param_group_of_decoder, hparams_fn=group_hparams_decoder)
         self.m3ae.store = self.store
-        for p in self.decoder.parameters():  # fp32 head: GEMMs read the master weights, not the bf16 shadow
-            if hasattr(p, "m3ae_c"):
-                del p.m3ae_c
         return self
 
     def features(self, batch):
@@ -293,7 +303,7 @@ class DecoderModel(_Base):
             parts += [out["multi_modal_image_feats"], out["multi_modal_text_feats"]]
         if cfg["mm_encoder_inputs_include_cls_feats"]:
             parts.append(out["multi_modal_cls_feats"].view(-1, 2, 768))
-        return torch.cat(parts, dim=1).float().contiguous()
+        return torch.cat(parts, dim=1).to(self.decoder.head_dtype).contiguous()
 
     def tokens_of(self, batch):
         if "decoder_tokens" in batch:

@@ -464,6 +464,11 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     B, Lq, D = q.shape
     Lk = k.shape[1]
     Dh = D // heads
+    if q.dtype == torch.bfloat16 and Dh != 64:
+        # the MFMA attention kernels are specialised for 64-wide heads; other widths (the decoder head's 96) take the fp32
+        # materialised-softmax kernels on fp32 copies of the projections: short sequences, a few % of that head's work
+        o32, lse = attn_forward(q.float(), k.float(), v.float(), heads, key_mask, pos_bias, scale, causal, dropout)
+        return o32.to(torch.bfloat16), lse
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     o = torch.empty((B, Lq, D), dtype=q.dtype, device=q.device)
     lse_stride = (Lq + 31) // 32 * 32
@@ -484,6 +489,14 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     B, Lq, D = q.shape
     Lk = k.shape[1]
     Dh = D // heads
+    if q.dtype == torch.bfloat16 and Dh != 64:   # fp32 detour, as in attn_forward
+        f = [t.float() for t in (q, k, v, o, do)]
+        g = [torch.empty_like(t) for t in f[:3]]
+        attn_backward(f[0], f[1], f[2], f[3].contiguous(), lse, f[4].contiguous(), g[0], g[1], g[2], heads, key_mask,
+                      pos_bias, scale, causal, d_pos_bias, dropout)
+        for dst, src in zip((dq, dk, dv), g):
+            dst.copy_(src)
+        return
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     assert do.stride() == o.stride() and dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse.shape[-1], _dt(q))

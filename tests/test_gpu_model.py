@@ -418,7 +418,7 @@ def test_tiny_decoder_generative_head_against_reference_fixture(mode):
     b["decoder_tokens"] = torch.from_numpy(g["tokens"]).cuda()
     enc = m.features(b)
     tol = dict(rtol=1e-3, atol=1e-5) if mode == "fp32" else dict(rtol=5e-2, atol=2e-2)
-    np.testing.assert_allclose(enc.cpu().numpy(), g["cls"], **tol)
+    np.testing.assert_allclose(enc.float().cpu().numpy(), g["cls"], **tol)
     m.store.zero_grad()
     out = m.training_step(b)
     loss = out["loss"]
@@ -433,6 +433,19 @@ def test_tiny_decoder_generative_head_against_reference_fixture(mode):
     # the reference's dead layers: present in the state_dict, outside the optimizer
     for n in g["trainable_nograd"].tolist():
         assert params[n].grad is None and not params[n].requires_grad
+    if mode == "bf16":
+        # perf mode: the head runs on the bf16 MFMA GEMMs (96-wide heads: fp32 attention kernels on fp32 copies)
+        from m3ae_amd import ops
+        tin = torch.from_numpy(g["tokens"][:, :-1]).cuda()
+        feats = torch.from_numpy(g["cls"]).cuda()
+        logits = m.decoder(tin.masked_fill(tin == 102, 0), (tin != 102) & (tin != 0), feats)
+        assert logits.dtype == torch.bfloat16 and ops.last_gemm_path().startswith("mfma")
+        ref = g["logits"]
+        assert np.abs(logits.detach().float().cpu().numpy() - ref).max() < 0.03 * max(1.0, np.abs(ref).max())
+        m.decoder.max_len = 16
+        a, c = m.decoder.search_path(feats), m.decoder.search_path(feats, use_cache=False)
+        np.testing.assert_array_equal(a.cpu().numpy(), c.cpu().numpy())   # cached rows = full-prefix passes, bf16 too
+        assert (a.cpu().numpy() == g["greedy"]).mean() > 0.9              # and the reference's tokens up to bf16 ties
     if mode == "fp32":
         m.current_tasks = []
         logits = m.decoder(torch.from_numpy(g["tokens"][:, :-1]).cuda().masked_fill(
