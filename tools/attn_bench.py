@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(ROOT, "mm-vqa-healthcare_amd"))
 import torch  # noqa: E402
 from m3ae_amd import ops, _lib  # noqa: E402
 
+if os.environ.get("M3AE_LIB"):   # A/B against another build of the library
+    _lib.LIB_PATH = os.environ["M3AE_LIB"]
+
 B, H, D = int(os.environ.get("B", 64)), 12, 768
 
 
@@ -22,7 +25,8 @@ def time_it(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-for (Lq, Lk, masked) in [(577, 577, False), (32, 577, False), (577, 32, True), (32, 32, True)]:
+SHAPES = [(577, 577, False), (577, 577, False), (32, 577, False), (577, 32, True), (32, 32, True)]   # first line = warm-up
+for (Lq, Lk, masked) in (SHAPES[:2] if os.environ.get("SELF_ONLY") else SHAPES):
     dev = "cuda"
     mask = None
     if masked:
