@@ -368,6 +368,11 @@ __global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP
         if (qi[n] < a.Lq) {
             store_rows(a.o + b * a.o_sb + qi[n] * a.o_sl + head * 64, o[n][0], o[n][1], 1.0f / ltot, h);
             if (h == 0) a.lse[(b * a.H + head) * a.lse_stride + qi[n]] = m[n] + log2f(ltot);
+        } else if (h == 0 && qi[n] < a.lse_stride) {
+            // padding rows of the log-sum-exp table (Lq .. lse_stride - 1, inside the last active wave's 32 rows): the
+            // backward tiles read them (p = exp2(x - lse) of a clamped row, masked to 0 afterwards) -- they must be finite,
+            // and the caller no longer zero-fills the table
+            a.lse[(b * a.H + head) * a.lse_stride + qi[n]] = 0.f;
         }
     }
 }
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             for (int j = 0; j < 8; ++j) dlt = fmaf(bf2f((bf16_t)of[j]), bf2f((bf16_t)dof[ks][j]), dlt);
         }
         dlt += __shfl_xor(dlt, 32, 64);
-        if (h == 0 && active && qi < a.Lq) a.delta[(b * a.H + head) * a.lse_stride + qi] = dlt;
+        if (h == 0 && active && qi < a.lse_stride)   // padding rows (>= Lq): 0, the caller does not zero-fill the table
+            a.delta[(b * a.H + head) * a.lse_stride + qi] = qi < a.Lq ? dlt : 0.f;
     }
 
     const bf16_t* kbase = a.k + b * a.k_sb + head * 64;

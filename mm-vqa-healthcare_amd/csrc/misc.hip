@@ -84,6 +84,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int
     }
 }
 
+// Whole-row form for contiguous bf16 / fp32 matrices with N % 8 == 0 and N / 8 <= 512: a workgroup of P * R threads (P = N / 8
+// 16-byte pieces per row, R rows per pass) reads R WHOLE rows per pass -- one contiguous stretch of memory -- and every
+// thread keeps its column group; four passes in flight per thread.  (The 256-column form above reads 512 B of each row per
+// workgroup and ran at 2.5 TB/s on 147712 x 768; profiles/r02_colsum.log.)
+template <typename T>
+__global__ __launch_bounds__(512) void colsum_rows_kernel(const T* x, float* out, int64_t M, int P, int R, int64_t rows_per) {
+    extern __shared__ float cred[];   // [R][P * 8]
+    const int t = threadIdx.x;
+    const int pc = t % P, rl = t / P;
+    const int64_t N = (int64_t)P * 8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+    int64_t r1 = r0 + rows_per;
+    if (r1 > M) r1 = M;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0 + rl;
+    const T* xp = x + pc * 8;
+    for (; r + 3 * R < r1; r += 4 * R) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ld8<T>(xp + (r + (int64_t)u * R) * N, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[u][k];
+    }
+    for (; r < r1; r += R) {
+        float v[8];
+        ld8<T>(xp + r * N, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cred[(int64_t)rl * N + pc * 8 + k] = acc[k];
+    __syncthreads();
+    for (int c = t; c < N; c += blockDim.x) {
+        float sum = 0.f;
+        for (int q = 0; q < R; ++q) sum += cred[(int64_t)q * N + c];
+        atomicAdd(out + c, sum);
+    }
+}
+
 // ---- RoBERTa embeddings ------------------------------------------------------------------------------------
 // one workgroup per sample: position ids by a serial scan over S (S <= 512), then D-wide gathers
 template <typename T>
@@ -410,6 +451,17 @@ extern "C" int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int6
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(out, 0, N * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
+    }
+    if (N % 8 == 0 && ldx == N && N / 8 <= 512 && M >= 4096 && ((((uintptr_t)x) & 15) == 0) &&
+        (dtype == M3AE_BF16 || dtype == M3AE_F32)) {
+        const int P = (int)(N / 8), R = 512 / P;
+        int64_t nwg = 2048;                      // 8 workgroups per CU
+        int64_t rows_per = cdiv(cdiv(M, nwg), (int64_t)4 * R) * 4 * R;   // whole unrolled passes
+        nwg = cdiv(M, rows_per);
+        const size_t lds = (size_t)R * N * sizeof(float);
+        DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_rows_kernel<T>), dim3((unsigned)nwg), dim3((unsigned)(P * R)), lds, s,
+                                            (const T*)x, out, M, P, R, rows_per));
+        return hip_launch_status();
     }
     const int64_t col_blocks = cdiv(N, 256);
     int64_t chunks = cdiv(1024, col_blocks);  // ~1024 workgroups in flight

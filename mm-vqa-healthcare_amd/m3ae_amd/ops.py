@@ -472,7 +472,8 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     o = torch.empty((B, Lq, D), dtype=q.dtype, device=q.device)
     lse_stride = (Lq + 31) // 32 * 32
-    lse = torch.zeros((B, heads, lse_stride), dtype=torch.float32, device=q.device)  # padding rows stay finite
+    # bf16 kernels write every row of the table, padding rows (>= Lq) included; the fp32 path leaves it untouched
+    lse = (torch.empty if q.dtype == torch.bfloat16 else torch.zeros)((B, heads, lse_stride), dtype=torch.float32, device=q.device)
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
     if dropout is not None and dropout[0] > 0:
         d.dropout_p, d.dropout_seed = dropout
@@ -500,7 +501,8 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     scale = (1.0 / math.sqrt(Dh)) if scale is None else scale
     assert do.stride() == o.stride() and dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse.shape[-1], _dt(q))
-    delta = torch.zeros_like(lse)  # rows Lq .. lse_stride-1 are padding: they must stay finite (0 * NaN in the dK/dV tile)
+    # rows Lq .. lse_stride-1 are padding and must stay finite (0 * NaN in the dK/dV tile): the dQ kernel writes them as 0
+    delta = torch.empty_like(lse) if q.dtype == torch.bfloat16 else torch.zeros_like(lse)
     d.d_o, d.dq, d.dk, d.dv, d.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
     if dropout is not None and dropout[0] > 0:
