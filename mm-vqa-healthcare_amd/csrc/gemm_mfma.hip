@@ -895,8 +895,29 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
 // barrier; B(c+3) / A(c+3) issued in phases 2c / 2c+1, counted vmcnt(8) in the odd phase.  Split over the reduction
 // with fp32 atomics; the bias gradient rides on a ones-fragment MFMA in the first column tile's waves.
 // Ring depth: a 5-slot ring (160 KiB, three chunks in flight behind the one awaited) measured the same as 4 slots on every
-// wgrad shape of the step (r02, profiles/r02_tn_ring_depth.log): the kernel is not waiting on load latency.
+// wgrad shape of the step (r02, profiles/r02_tn_ring_depth.log): the kernel is not waiting on load latency.  An L2 prefetch
+// of chunk c + 4 / 8 / 16 (one 4-byte LDS-DMA per 64-B segment, one instruction per wave and chunk) made every shape 9 %
+// SLOWER (profiles/r02_tn_l2_prefetch.log): one more LDS-DMA instruction per wave and chunk (5 instead of 4) costs ~240
+// clocks of the chunk -- what bounds the loop is the issue of the DMA instructions themselves (in-loop stamps,
+// tools/tn_trace.py: a wave row's "fragment reads + 2 DMA issues" phase takes 650-1000 clocks against 420 for the other
+// row's 16 MFMAs).  Moving the two DMA issues of a phase INTO the wave's own MFMA cluster (after its first 4 MFMAs) is 10 %
+// slower again (profiles/r02_tn_dma_in_mfma.log): a 1-KiB piece costs its wave ~250 clocks wherever it is issued while
+// eight waves stage 32 KiB per chunk -- ~30 B / clk / CU of LDS-DMA issue, the same ceiling the fused cross-attention
+// kernels run into.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef M3AE_TN_TRACE   // diagnostic build only: in-loop stamps of one chunk of the TN ping-pong kernel
+__device__ uint64_t g_tn_trace[512 * 2 * 16];
+#define TN_STAMP(k) do { if (tn_tr) g_tn_trace[((size_t)blockIdx.x * 2 + wr) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int m3ae_tn_trace_dump(uint64_t* out) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tn_trace), sizeof(uint64_t) * 512 * 2 * 16);
+    static uint64_t zeros[512 * 2 * 16];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tn_trace), zeros, sizeof(zeros));
+    return 0;
+}
+#else
+#define TN_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -945,6 +966,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
     if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
 
     for (int c = 0; c < nc; ++c) {
+#ifdef M3AE_TN_TRACE
+        const bool tn_tr = (c == 64 || c == 65) && lane == 0 && wc == 0 && blockIdx.x < 512;
+        if (tn_tr && c == 65) g_tn_trace[((size_t)blockIdx.x * 2 + wr) * 16 + 8] = __builtin_readcyclecounter();
+#undef TN_STAMP
+#define TN_STAMP(k) do { if (tn_tr && c == 64) g_tn_trace[((size_t)blockIdx.x * 2 + wr) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#endif
+        TN_STAMP(0);
         const char* At = smem + (c & 3) * SLOT;
         const char* Bt = At + A_BYTES;
         char* nxt = smem + ((c + 3) & 3) * SLOT;
@@ -958,17 +986,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
         for (int i = 0; i < 4; ++i) af[i] = tn_frag<256>(At, 0, wr * 128 + i * 16, lane);
         if (more) tn_stage<256, 2, NW>(a.B, a.ldb, r3, r_end, n0, nxt + A_BYTES, wave, lane);
         PP_FENCE();
+        TN_STAMP(1);
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
+        TN_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        }
         if (do_rowsum) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -977,8 +1008,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         PP_FENCE();
+        TN_STAMP(3);
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
+        TN_STAMP(4);
         // ---------------- phase 2c + 1: output rows 64..127 (the B fragments stay in registers)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = tn_frag<256>(At, 0, wr * 128 + 64 + i * 16, lane);
@@ -990,17 +1023,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         PP_FENCE();
+        TN_STAMP(5);
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
+        TN_STAMP(6);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[4 + i][j], 0, 0, 0);
+        }
         if (do_rowsum) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
