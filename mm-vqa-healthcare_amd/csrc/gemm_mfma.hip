@@ -903,7 +903,9 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
 // row's 16 MFMAs).  Moving the two DMA issues of a phase INTO the wave's own MFMA cluster (after its first 4 MFMAs) is 10 %
 // slower again (profiles/r02_tn_dma_in_mfma.log): a 1-KiB piece costs its wave ~250 clocks wherever it is issued while
 // eight waves stage 32 KiB per chunk -- ~30 B / clk / CU of LDS-DMA issue, the same ceiling the fused cross-attention
-// kernels run into.
+// kernels run into.  Starting the tiles that share an operand panel apart in time (so that the later ones
+// find the panel's lines in L2) changes nothing either: up to 11 us of skew is caught up within the launch, then the tiles
+// run in step again (profiles/r02_tn_stagger.log).
 // ---------------------------------------------------------------------------------------------------------
 #ifdef M3AE_TN_TRACE   // diagnostic build only: in-loop stamps of one chunk of the TN ping-pong kernel
 __device__ uint64_t g_tn_trace[512 * 2 * 16];
