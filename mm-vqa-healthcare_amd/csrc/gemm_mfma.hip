@@ -905,7 +905,9 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
 // eight waves stage 32 KiB per chunk -- ~30 B / clk / CU of LDS-DMA issue, the same ceiling the fused cross-attention
 // kernels run into.  Starting the tiles that share an operand panel apart in time (so that the later ones
 // find the panel's lines in L2) changes nothing either: up to 11 us of skew is caught up within the launch, then the tiles
-// run in step again (profiles/r02_tn_stagger.log).
+// run in step again (profiles/r02_tn_stagger.log).  Nor does the length of the contiguous global runs of a piece: rotating a
+// row by tn_swz(row) slots instead of XOR-permuting its 16-B chunks (same bank-conflict freedom, 288-480-B runs instead of
+// 32-B pairs) measured 825 / 868 / 854 / 726 TFLOP/s against 826-834 / 868-882 / 860-863 / 735 on the four wgrad shapes.
 // ---------------------------------------------------------------------------------------------------------
 #ifdef M3AE_TN_TRACE   // diagnostic build only: in-loop stamps of one chunk of the TN ping-pong kernel
 __device__ uint64_t g_tn_trace[512 * 2 * 16];
