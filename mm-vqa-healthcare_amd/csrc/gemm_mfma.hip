@@ -908,6 +908,10 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
 // run in step again (profiles/r02_tn_stagger.log).  Nor does the length of the contiguous global runs of a piece: rotating a
 // row by tn_swz(row) slots instead of XOR-permuting its 16-B chunks (same bank-conflict freedom, 288-480-B runs instead of
 // 32-B pairs) measured 825 / 868 / 854 / 726 TFLOP/s against 826-834 / 868-882 / 860-863 / 735 on the four wgrad shapes.
+// And staging through REGISTERS instead of LDS-DMA (global_load_dwordx4 in iteration c, ds_write_b128 in c + 1, 16 staging
+// registers per wave -- all the kernel has left) is 4 % slower: 784 / 825-834 / 808-811 / 707-714 against 818 / 857-863 /
+// 849-853 / 732-736 (bit-identical results).  For calibration: torch.matmul (hipBLASLt) runs these four wgrad shapes at
+// 699 / 721 / 550 / 347 TFLOP/s on the same box (tools/vendor_gemm_ref.py, profiles/r02_vendor_gemm_reference.log).
 // ---------------------------------------------------------------------------------------------------------
 #ifdef M3AE_TN_TRACE   // diagnostic build only: in-loop stamps of one chunk of the TN ping-pong kernel
 __device__ uint64_t g_tn_trace[512 * 2 * 16];
