@@ -1,0 +1,154 @@
+// EXPERIMENT (not part of libm3ae_hip.so, not on the product path): the NT GEMM tile the vendor library uses on gfx950 --
+// 256 x 256 output tile on FOUR waves of 128 x 128 (256 fp32 accumulators per lane, one wave per SIMD), operands staged
+// through REGISTERS (global_load_dwordx4 now, ds_write_b128 two chunks later) instead of LDS-DMA, fragments of the next
+// chunk read under the current chunk's MFMAs.  C[M][N] (bf16) = A[M][K] . B[N][K]^T, M % 256 == N % 256 == 0, K % 32 == 0,
+// K >= 128.  Plain store epilogue.  Built and timed by tools/experimental/nt_w4_bench.py; see DESIGN.md 9.
+#include <type_traits>
+#include "common.h"
+#include "mfma_tiles.h"
+
+namespace {
+
+constexpr int CK = 32, TILE_BYTES = 256 * CK * 2, SLOT = 2 * TILE_BYTES, NS = 3;
+
+struct W4Args { const bf16_t* A; const bf16_t* B; bf16_t* C; int M, N, K, lda, ldb, ldc; };
+
+// piece q of the wave's 4 + 4 pieces of a chunk (q < 4: A rows, else B rows; 16 rows x 64 B per piece): uniform base
+// (scalar registers) + one 32-bit per-lane byte offset per operand
+DEVINL void issue1(const char* ba, const char* bb, int64_t sa, int64_t sb, uint32_t va, uint32_t vb, int kc, int q, u32x4* st) {
+    st[q] = q < 4 ? *(const u32x4*)(ba + (q * sa + (int64_t)kc * (CK * 2)) + va)
+                  : *(const u32x4*)(bb + ((q - 4) * sb + (int64_t)kc * (CK * 2)) + vb);
+}
+DEVINL void commit1(char* slot, int wave, int lane, int q, const u32x4* st) {
+    *(u32x4*)(slot + (q < 4 ? 0 : TILE_BYTES) + ((q & 3) * 4 + wave) * 1024 + lane * 16) = st[q];
+}
+
+// accumulators pinned to AGPRs ("+a"): with the builtin the register allocator shuffled accumulator quads between AGPRs
+// and VGPRs around every MFMA of the interleaved loop
+DEVINL void mfma16(f32x4& c, s16x8 a, s16x8 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // the library's tile order: XCD-contiguous id ranges, column tiles in groups (all of them up to 9, else 6), row-major in a group
+    const unsigned tiles_n = (unsigned)(a.N / 256), tiles_m = gridDim.x / tiles_n;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned GC = tiles_n <= 9 ? tiles_n : 6, per_group = tiles_m * GC, grp = wg / per_group, first = grp * GC;
+    const unsigned gc = tiles_n - first < GC ? tiles_n - first : GC, local = wg - grp * per_group;
+    const int64_t m0 = (int64_t)(local / gc) * 256, n0 = (int64_t)(first + local % gc) * 256;
+    const int nc = a.K / CK;
+
+    // staging: piece q of the wave = tile rows (4 q + wave) * 16 + lane / 4, 16-B chunk (lane & 3) ^ swz(row); the swizzle
+    // depends on lane only (row >> 2 = 4 seg + lane / 16)
+    const int srow = wave * 16 + (lane >> 2);
+    const int schunk = (lane & 3) ^ nt_swz<CK>(srow);
+    const char* pa = (const char*)(a.A + m0 * a.lda);   // uniform
+    const char* pb = (const char*)(a.B + n0 * a.ldb);
+    const uint32_t va = (uint32_t)(srow * a.lda + schunk * 8) * 2u, vb = (uint32_t)(srow * a.ldb + schunk * 8) * 2u;
+    const int64_t sa = (int64_t)64 * a.lda * 2, sb = (int64_t)64 * a.ldb * 2;   // bytes between the wave's pieces
+
+    // fragment offsets inside a slot: A rows wr * 128 + 16 i + (lane & 15), chunk lane >> 4; B rows wc * 128 + 16 j + ...
+    const int fr = lane & 15, fc = lane >> 4;
+    int offa[8], offb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        offa[i] = nt_frag_off<CK>(wr * 128 + 16 * i + fr, fc);
+        offb[i] = TILE_BYTES + nt_frag_off<CK>(wc * 128 + 16 * i + fr, fc);
+    }
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 st[2][8];
+    s16x8 fa[2][8], fb[8];
+    // prologue: chunks 0 and 1 into LDS, chunks 2 and 3 into the staging registers
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 0, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 1, q, st[1]); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { commit1(smem, wave, lane, q, st[0]); commit1(smem + SLOT, wave, lane, q, st[1]); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 2, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 3, q, st[1]); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[0][i] = nt_frag_at(smem, offa[i]); fb[i] = nt_frag_at(smem, offb[i]); }
+
+    int cur = 0;   // c % 3
+    // One chunk: 8 groups of 8 MFMAs (output column block g; the B fragment of a group is dead after it and re-read IN PLACE
+    // for the next chunk one group later).  Groups 0-3 also carry the next chunk's 8 A-fragment reads (other register set) and
+    // the 8 LDS stores of chunk c + 2 (staged two iterations ago); groups 4-7 the 8 global loads of chunk c + 4.  Before the
+    // barrier only the LDS stores have to be complete: 4 fragment reads are issued behind the last of them.
+#define W4_STEP(c, p, NEXT, C2, C4) do { \
+        const int nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1; \
+        const char* sn = smem + nx * SLOT; \
+        char* sw = smem + nn * SLOT; \
+        _Pragma("unroll") \
+        for (int g = 0; g < 8; ++g) { \
+            _Pragma("unroll") \
+            for (int i = 0; i < 4; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
+            if (g < 4) { \
+                if (NEXT) { fa[(p) ^ 1][2 * g] = nt_frag_at(sn, offa[2 * g]); fa[(p) ^ 1][2 * g + 1] = nt_frag_at(sn, offa[2 * g + 1]); } \
+                if (C2) { commit1(sw, wave, lane, 2 * g, st[p]); commit1(sw, wave, lane, 2 * g + 1, st[p]); } \
+            } else if (C4) { \
+                issue1(pa, pb, sa, sb, va, vb, (c) + 4, 2 * (g - 4), st[p]); issue1(pa, pb, sa, sb, va, vb, (c) + 4, 2 * (g - 4) + 1, st[p]); \
+            } \
+            _Pragma("unroll") \
+            for (int i = 4; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
+            if (NEXT) fb[g] = nt_frag_at(sn, offb[g]); \
+            __builtin_amdgcn_sched_barrier(0); \
+        } \
+        if (NEXT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier(); \
+        cur = nx; \
+    } while (0)
+    int c = 0;
+    for (; c + 4 < nc; c += 2) {   // nc even, >= 4: steady state, no conditionals
+        W4_STEP(c, 0, true, true, true);
+        W4_STEP(c + 1, 1, true, true, true);
+    }
+    // the last four chunks: c = nc - 4 .. nc - 1 (c even here)
+    W4_STEP(c, 0, true, true, false);
+    W4_STEP(c + 1, 1, true, true, false);
+    W4_STEP(c + 2, 0, true, false, false);
+    W4_STEP(c + 3, 1, false, false, false);
+
+    // ---- epilogue: 16-row slabs through LDS (the ring is free: every wave passed the last barrier), 16-B stores along rows
+    // lane holds C[row 16 i + (lane & 15)][cols 16 j + 4 (lane >> 4) .. + 3] (operands swapped in the MFMA)
+    constexpr int RS = 128 * 4 + 16;   // fp32 slab row stride (bytes)
+    char* slab = smem + wave * (16 * RS);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(f32x4*)(slab + fr * RS + (16 * j + 4 * fc) * 4) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int piece = lane + 64 * t, row = piece >> 4, c8 = piece & 15;
+            const f32x4 v0 = *(const f32x4*)(slab + row * RS + c8 * 32);
+            const f32x4 v1 = *(const f32x4*)(slab + row * RS + c8 * 32 + 16);
+            u32x4 o = {pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3])};
+            *(u32x4*)(a.C + (m0 + wr * 128 + 16 * i + row) * a.ldc + n0 + wc * 128 + c8 * 8) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+extern "C" int nt_w4_launch(const void* A, const void* B, void* C, int M, int N, int K, void* stream) {
+    if (M % 256 || N % 256 || K % 64 || K < 128) return -1;
+    W4Args a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, K, K, N};
+    static bool set = false;
+    const int lds = NS * SLOT;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(nt_w4_kernel, dim3((unsigned)((M / 256) * (N / 256))), dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
