@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int CK = 32, TILE_BYTES = 256 * CK * 2, SLOT = 2 * TILE_BYTES, NS = 3;
+constexpr int CK = 32, TILE_BYTES = 256 * CK * 2, SLOT = 2 * TILE_BYTES, NS = 5;
 
 struct W4Args { const bf16_t* A; const bf16_t* B; bf16_t* C; int M, N, K, lda, ldb, ldc; };
 
@@ -70,57 +70,67 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
 
     u32x4 st[2][8];
     s16x8 fa[2][8], fb[8];
-    // prologue: chunks 0 and 1 into LDS, chunks 2 and 3 into the staging registers
+    // prologue: chunks 0, 1, 2 into LDS, chunks 3 and 4 into the staging registers
 #pragma unroll
     for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 0, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 1, q, st[1]); }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { commit1(smem, wave, lane, q, st[0]); commit1(smem + SLOT, wave, lane, q, st[1]); }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 2, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 3, q, st[1]); }
+    for (int q = 0; q < 8; ++q) issue1(pa, pb, sa, sb, va, vb, 2, q, st[0]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) commit1(smem + 2 * SLOT, wave, lane, q, st[0]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 3, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 4, q, st[1]); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[0][i] = nt_frag_at(smem, offa[i]); fb[i] = nt_frag_at(smem, offb[i]); }
 
-    int cur = 0;   // c % 3
+    int cur = 0;   // c % 5
     // One chunk: 8 groups of 8 MFMAs (output column block g; the B fragment of a group is dead after it and re-read IN PLACE
-    // for the next chunk one group later).  Groups 0-3 also carry the next chunk's 8 A-fragment reads (other register set) and
-    // the 8 LDS stores of chunk c + 2 (staged two iterations ago); groups 4-7 the 8 global loads of chunk c + 4.  Before the
-    // barrier only the LDS stores have to be complete: 4 fragment reads are issued behind the last of them.
-#define W4_STEP(c, p, NEXT, C2, C4) do { \
-        const int nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1; \
+    // for the next chunk).  Groups 0-3 also carry the next chunk's 8 A-fragment reads (other register set) and the 8 LDS
+    // stores of chunk c + 3 (staged two iterations ago); groups 4-7 the 8 global loads of chunk c + 5.  Five LDS slots: a
+    // chunk is stored three chunks before it is read, so ONE barrier per TWO chunks orders both the stores against the reads
+    // that follow and the reads against the stores that reuse the slot.
+#define W4_STEP(c, p, NEXT, C3, C5) do { \
+        const int nx = cur == 4 ? 0 : cur + 1; \
+        const int n3 = cur + 3 >= 5 ? cur - 2 : cur + 3; \
         const char* sn = smem + nx * SLOT; \
-        char* sw = smem + nn * SLOT; \
+        char* sw = smem + n3 * SLOT; \
         _Pragma("unroll") \
         for (int g = 0; g < 8; ++g) { \
             _Pragma("unroll") \
             for (int i = 0; i < 4; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
             if (g < 4) { \
                 if (NEXT) { fa[(p) ^ 1][2 * g] = nt_frag_at(sn, offa[2 * g]); fa[(p) ^ 1][2 * g + 1] = nt_frag_at(sn, offa[2 * g + 1]); } \
-                if (C2) { commit1(sw, wave, lane, 2 * g, st[p]); commit1(sw, wave, lane, 2 * g + 1, st[p]); } \
-            } else if (C4) { \
-                issue1(pa, pb, sa, sb, va, vb, (c) + 4, 2 * (g - 4), st[p]); issue1(pa, pb, sa, sb, va, vb, (c) + 4, 2 * (g - 4) + 1, st[p]); \
+                if (C3) { commit1(sw, wave, lane, 2 * g, st[p]); commit1(sw, wave, lane, 2 * g + 1, st[p]); } \
+            } else if (C5) { \
+                issue1(pa, pb, sa, sb, va, vb, (c) + 5, 2 * (g - 4), st[p]); issue1(pa, pb, sa, sb, va, vb, (c) + 5, 2 * (g - 4) + 1, st[p]); \
             } \
             _Pragma("unroll") \
             for (int i = 4; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
             if (NEXT) fb[g] = nt_frag_at(sn, offb[g]); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
-        if (NEXT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); \
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_s_barrier(); \
+        if ((p) == 1) { \
+            if (NEXT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+            __builtin_amdgcn_s_barrier(); \
+        } \
         cur = nx; \
     } while (0)
     int c = 0;
-    for (; c + 4 < nc; c += 2) {   // nc even, >= 4: steady state, no conditionals
+    for (; c + 6 < nc; c += 2) {   // nc even, >= 6: steady state, no conditionals
         W4_STEP(c, 0, true, true, true);
         W4_STEP(c + 1, 1, true, true, true);
     }
-    // the last four chunks: c = nc - 4 .. nc - 1 (c even here)
-    W4_STEP(c, 0, true, true, false);
+    // the last six chunks: c = nc - 6 .. nc - 1 (c even here)
+    W4_STEP(c, 0, true, true, true);
     W4_STEP(c + 1, 1, true, true, false);
-    W4_STEP(c + 2, 0, true, false, false);
-    W4_STEP(c + 3, 1, false, false, false);
+    W4_STEP(c + 2, 0, true, true, false);
+    W4_STEP(c + 3, 1, true, false, false);
+    W4_STEP(c + 4, 0, true, false, false);
+    W4_STEP(c + 5, 1, false, false, false);
 
     // ---- epilogue: 16-row slabs through LDS (the ring is free: every wave passed the last barrier), 16-B stores along rows
     // lane holds C[row 16 i + (lane & 15)][cols 16 j + 4 (lane >> 4) .. + 3] (operands swapped in the MFMA)
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
 }
 
 extern "C" int nt_w4_launch(const void* A, const void* B, void* C, int M, int N, int K, void* stream) {
-    if (M % 256 || N % 256 || K % 64 || K < 128) return -1;
+    if (M % 256 || N % 256 || K % 64 || K < 192) return -1;
     W4Args a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, K, K, N};
     static bool set = false;
     const int lds = NS * SLOT;
