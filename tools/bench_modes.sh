@@ -4,7 +4,7 @@ mkdir -p gpurun_out/modes
 run() {  # name args...
   local name=$1; shift
   echo "=== $name"
-  timeout -k 10 420 python bench.py --no-cpu-baseline --no-roofline "$@" > gpurun_out/modes/$name.log 2>&1
+  timeout -k 10 420 python bench.py --no-cpu-baseline --no-roofline --no-secondary "$@" > gpurun_out/modes/$name.log 2>&1
   local rc=$?
   grep '^{' gpurun_out/modes/$name.log | tail -1 > gpurun_out/modes/$name.json
   echo "=== $name rc=$rc $(python -c "import json,sys; d=json.load(open('gpurun_out/modes/$name.json')); print(d['value'], d['unit'], d['ms_per_step'], 'ms')" 2>/dev/null)"
