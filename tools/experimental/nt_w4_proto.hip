@@ -101,19 +101,17 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
         for (int g = 0; g < 8; ++g) { \
             _Pragma("unroll") \
             for (int i = 0; i < 4; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
-            if (g < 4) { \
-                if (NEXT) { fa[(p) ^ 1][2 * g] = nt_frag_at(sn, offa[2 * g]); fa[(p) ^ 1][2 * g + 1] = nt_frag_at(sn, offa[2 * g + 1]); } \
-                if (C3) { commit1(sw, wave, lane, 2 * g, st[p]); commit1(sw, wave, lane, 2 * g + 1, st[p]); } \
-            } else if (C5) { \
-                issue1(pa, pb, sa, sb, va, vb, (c) + 5, 2 * (g - 4), st[p]); issue1(pa, pb, sa, sb, va, vb, (c) + 5, 2 * (g - 4) + 1, st[p]); \
-            } \
+            if (NEXT) fa[(p) ^ 1][g] = nt_frag_at(sn, offa[g]); \
+            if (C3) commit1(sw, wave, lane, g, st[p]); \
+            if (C5 && g >= 1) issue1(pa, pb, sa, sb, va, vb, (c) + 5, g - 1, st[p]); \
             _Pragma("unroll") \
             for (int i = 4; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
             if (NEXT) fb[g] = nt_frag_at(sn, offb[g]); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
+        if (C5) issue1(pa, pb, sa, sb, va, vb, (c) + 5, 7, st[p]); \
         if ((p) == 1) { \
-            if (NEXT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); \
+            if (NEXT) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); \
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
             __builtin_amdgcn_s_barrier(); \
         } \
