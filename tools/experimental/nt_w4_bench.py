@@ -40,7 +40,7 @@ def w4(x, w, y, M, N, K):
     assert rc == 0, rc
 
 
-for M, N, K in [(2048, 1024, 384), (8192, 8192, 8192), (147712, 3072, 768), (147712, 2304, 768), (147712, 768, 768), (147712, 768, 3072)]:
+for M, N, K in [(2048, 1024, 384), (512, 512, 1024), (8192, 8192, 8192), (147712, 3072, 768), (147712, 2304, 768), (147712, 768, 768), (147712, 768, 3072)]:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

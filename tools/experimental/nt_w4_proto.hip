@@ -24,7 +24,14 @@ DEVINL void commit1(char* slot, int wave, int lane, int q, const u32x4* st) {
 }
 
 // accumulators pinned to AGPRs ("+a"): with the builtin the register allocator shuffled accumulator quads between AGPRs
-// and VGPRs around every MFMA of the interleaved loop
+// and VGPRs around every MFMA of the interleaved loop.
+// CAVEAT (why this stays an experiment): the compiler's hazard recognizer does not look inside inline asm.  A form of this
+// kernel with FOUR staging sets (256 VGPRs: fragment registers re-used for load addresses right after their last MFMA)
+// computed wrong sums in exactly the iterations that issue global loads (per-chunk probe: chunks of the steady state wrong,
+// chunks of the load-free tail right; not a waitcnt or barrier problem -- vmcnt(0) / a barrier per chunk change nothing) --
+// a write-after-read on MFMA source registers without the wait states a real MFMA instruction would get.  The two-set form
+// below (216 VGPRs) is bit-identical to the library's kernel on every tested shape, but the product version needs MFMAs the
+// hazard recognizer can see (the builtin, with the accumulators kept in place some other way) or hand-placed s_nops.
 DEVINL void mfma16(f32x4& c, s16x8 a, s16x8 b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
@@ -68,9 +75,9 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    u32x4 st[2][8];
-    s16x8 fa[2][8], fb[8];
-    // prologue: chunks 0, 1, 2 into LDS, chunks 3 and 4 into the staging registers
+    u32x4 st[2][8];          // chunks c + 3, c + 4 on their way through registers
+    s16x8 fa[8], fb[8];      // fragments, re-read IN PLACE (no second register set)
+    // prologue: chunks 0, 1, 2 into LDS, chunks 3 and 4 into the staging registers (chunk j lives in set (j + 1) & 1)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { issue1(pa, pb, sa, sb, va, vb, 0, q, st[0]); issue1(pa, pb, sa, sb, va, vb, 1, q, st[1]); }
 #pragma unroll
@@ -84,34 +91,47 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { fa[0][i] = nt_frag_at(smem, offa[i]); fb[i] = nt_frag_at(smem, offb[i]); }
+    for (int i = 0; i < 4; ++i) fa[i] = nt_frag_at(smem, offa[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = nt_frag_at(smem, offb[i]);
 
     int cur = 0;   // c % 5
-    // One chunk: 8 groups of 8 MFMAs (output column block g; the B fragment of a group is dead after it and re-read IN PLACE
-    // for the next chunk).  Groups 0-3 also carry the next chunk's 8 A-fragment reads (other register set) and the 8 LDS
-    // stores of chunk c + 3 (staged two iterations ago); groups 4-7 the 8 global loads of chunk c + 5.  Five LDS slots: a
-    // chunk is stored three chunks before it is read, so ONE barrier per TWO chunks orders both the stores against the reads
-    // that follow and the reads against the stores that reuse the slot.
-#define W4_STEP(c, p, NEXT, C3, C5) do { \
+    // One chunk = two halves of 8 sub-groups of 4 MFMAs: half h, sub-group g = output rows 64 h .. + 63, column block g.
+    //   first half  (0, g): g < 4 reads THIS chunk's second-half A fragment 4 + g (slot cur); every g stores piece g of chunk
+    //                       c + 3 (set c & 1, loaded two chunks ago) into slot (cur + 3) % 5;
+    //   second half (1, g): g < 4 reads the NEXT chunk's first-half A fragment g in place (its registers died with the first
+    //                       half); after its MFMAs B fragment g is re-read in place for the next chunk; every g loads piece g
+    //                       of chunk c + 5 into the set just stored.
+    // One barrier per two chunks (five slots, see above); before it only the LDS stores have to be complete: 12 reads follow.
+#define W4_STEP(c, SET, BAR, NEXT, C3, C5) do { \
         const int nx = cur == 4 ? 0 : cur + 1; \
         const int n3 = cur + 3 >= 5 ? cur - 2 : cur + 3; \
+        const char* sc = smem + cur * SLOT; \
         const char* sn = smem + nx * SLOT; \
         char* sw = smem + n3 * SLOT; \
         _Pragma("unroll") \
         for (int g = 0; g < 8; ++g) { \
             _Pragma("unroll") \
-            for (int i = 0; i < 4; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
-            if (NEXT) fa[(p) ^ 1][g] = nt_frag_at(sn, offa[g]); \
-            if (C3) commit1(sw, wave, lane, g, st[p]); \
-            if (C5 && g >= 1) issue1(pa, pb, sa, sb, va, vb, (c) + 5, g - 1, st[p]); \
+            for (int i = 0; i < 2; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
+            if (g < 4) fa[4 + g] = nt_frag_at(sc, offa[4 + g]); \
+            if (C3) commit1(sw, wave, lane, g, st[SET]); \
             _Pragma("unroll") \
-            for (int i = 4; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[p][i]); \
+            for (int i = 2; i < 4; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
+            __builtin_amdgcn_sched_barrier(0); \
+        } \
+        _Pragma("unroll") \
+        for (int g = 0; g < 8; ++g) { \
+            if (NEXT && g < 4) fa[g] = nt_frag_at(sn, offa[g]); \
+            _Pragma("unroll") \
+            for (int i = 4; i < 6; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
+            if (C5) issue1(pa, pb, sa, sb, va, vb, (c) + 5, g, st[SET]); \
+            _Pragma("unroll") \
+            for (int i = 6; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
             if (NEXT) fb[g] = nt_frag_at(sn, offb[g]); \
             __builtin_amdgcn_sched_barrier(0); \
         } \
-        if (C5) issue1(pa, pb, sa, sb, va, vb, (c) + 5, 7, st[p]); \
-        if ((p) == 1) { \
-            if (NEXT) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); \
+        if (BAR) { \
+            if (NEXT) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); \
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
             __builtin_amdgcn_s_barrier(); \
         } \
@@ -119,16 +139,16 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
     } while (0)
     int c = 0;
     for (; c + 6 < nc; c += 2) {   // nc even, >= 6: steady state, no conditionals
-        W4_STEP(c, 0, true, true, true);
-        W4_STEP(c + 1, 1, true, true, true);
+        W4_STEP(c, 0, false, true, true, true);
+        W4_STEP(c + 1, 1, true, true, true, true);
     }
-    // the last six chunks: c = nc - 6 .. nc - 1 (c even here)
-    W4_STEP(c, 0, true, true, true);
-    W4_STEP(c + 1, 1, true, true, false);
-    W4_STEP(c + 2, 0, true, true, false);
-    W4_STEP(c + 3, 1, true, false, false);
-    W4_STEP(c + 4, 0, true, false, false);
-    W4_STEP(c + 5, 1, false, false, false);
+    // the last six chunks: c = nc - 6 .. nc - 1
+    W4_STEP(c, 0, false, true, true, true);
+    W4_STEP(c + 1, 1, true, true, true, false);
+    W4_STEP(c + 2, 0, false, true, true, false);
+    W4_STEP(c + 3, 1, true, true, false, false);
+    W4_STEP(c + 4, 0, false, true, false, false);
+    W4_STEP(c + 5, 1, true, false, false, false);
 
     // ---- epilogue: 16-row slabs through LDS (the ring is free: every wave passed the last barrier), 16-B stores along rows
     // lane holds C[row 16 i + (lane & 15)][cols 16 j + 4 (lane >> 4) .. + 3] (operands swapped in the MFMA)
