@@ -25,13 +25,10 @@ DEVINL void commit1(char* slot, int wave, int lane, int q, const u32x4* st) {
 
 // accumulators pinned to AGPRs ("+a"): with the builtin the register allocator shuffled accumulator quads between AGPRs
 // and VGPRs around every MFMA of the interleaved loop.
-// CAVEAT (why this stays an experiment): the compiler's hazard recognizer does not look inside inline asm.  A form of this
-// kernel with FOUR staging sets (256 VGPRs: fragment registers re-used for load addresses right after their last MFMA)
-// computed wrong sums in exactly the iterations that issue global loads (per-chunk probe: chunks of the steady state wrong,
-// chunks of the load-free tail right; not a waitcnt or barrier problem -- vmcnt(0) / a barrier per chunk change nothing) --
-// a write-after-read on MFMA source registers without the wait states a real MFMA instruction would get.  The two-set form
-// below (216 VGPRs) is bit-identical to the library's kernel on every tested shape, but the product version needs MFMAs the
-// hazard recognizer can see (the builtin, with the accumulators kept in place some other way) or hand-placed s_nops.
+// CAVEAT: nothing inside an inline-asm string is visible to the compiler's hazard recognizer or its scheduler; the MFMA
+// operands here come from LDS reads (waitcnt-tracked) and the accumulators never leave their AGPRs inside the loop, and the
+// results are bit-identical to the library's kernel on every tested shape -- but a product version should be re-audited at
+// the .s level after every change (one such audit found the loop / tail accumulator copy problem described at the loop).
 DEVINL void mfma16(f32x4& c, s16x8 a, s16x8 b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
             if (NEXT && g < 4) fa[g] = nt_frag_at(sn, offa[g]); \
             _Pragma("unroll") \
             for (int i = 4; i < 6; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
-            if (C5) issue1(pa, pb, sa, sb, va, vb, (c) + 5, g, st[SET]); \
+            if (C5) issue1(pa, pb, sa, sb, va, vb, ((c) + 5 < nc ? (c) + 5 : nc - 1), g, st[SET]); \
             _Pragma("unroll") \
             for (int i = 6; i < 8; ++i) mfma16(acc[i][g], fb[g], fa[i]); \
             if (NEXT) fb[g] = nt_frag_at(sn, offb[g]); \
@@ -137,18 +134,16 @@ __global__ __launch_bounds__(256, 1) void nt_w4_kernel(W4Args a) {
         } \
         cur = nx; \
     } while (0)
-    int c = 0;
-    for (; c + 6 < nc; c += 2) {   // nc even, >= 6: steady state, no conditionals
+    // No specialised tail: chunk indices past the end are clamped to the last chunk (a few redundant loads, LDS stores into
+    // slots nobody reads again, one unused fragment read).  With a separate tail the compiler assigned the 256 accumulator
+    // registers differently in the loop and in the tail and the accvgpr copy sequence between them lost accumulator values
+    // (a four-staging-set form showed it: per-chunk probe in profiles/r02_nt_w4_prototype.log).
+    for (int c = 0; c < nc; c += 2) {   // nc even
         W4_STEP(c, 0, false, true, true, true);
         W4_STEP(c + 1, 1, true, true, true, true);
     }
-    // the last six chunks: c = nc - 6 .. nc - 1
-    W4_STEP(c, 0, false, true, true, true);
-    W4_STEP(c + 1, 1, true, true, true, false);
-    W4_STEP(c + 2, 0, false, true, true, false);
-    W4_STEP(c + 3, 1, true, true, false, false);
-    W4_STEP(c + 4, 0, false, true, false, false);
-    W4_STEP(c + 5, 1, true, false, false, false);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: 16-row slabs through LDS (the ring is free: every wave passed the last barrier), 16-B stores along rows
     // lane holds C[row 16 i + (lane & 15)][cols 16 j + 4 (lane >> 4) .. + 3] (operands swapped in the MFMA)
