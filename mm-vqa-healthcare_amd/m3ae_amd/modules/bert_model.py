@@ -154,7 +154,8 @@ class BertCrossLayer(nn.Module):
             self._anchors = tuple(self.parameters())
         self._bp.pdrop = self.drop_rate if self.training else 0.0
         # forward-only calls always take the fused cross-attention sub-block; training takes it with its fused backward
-        self._bp.fused_cross = (not torch.is_grad_enabled()) or ops.XATTN_TRAIN != "off"
+        self._bp.fused_cross = (not torch.is_grad_enabled()) or (ops.XATTN_TRAIN != "off" and
+                                                                 hidden_states.shape[0] >= ops.XATTN_TRAIN_MIN_BATCH)
         return ops.BertCrossLayerFn.apply(hidden_states, encoder_hidden_states, attention_mask, encoder_attention_mask,
                                           self._bp, *self._anchors)
 

@@ -583,6 +583,10 @@ def _bdata(b):
 XATTN = os.environ.get("M3AE_XATTN", "auto")
 # training (a backward will be asked): "auto" = fused forward + fused backward, "off" = the composition
 XATTN_TRAIN = os.environ.get("M3AE_XATTN_TRAIN", "auto")
+# ... from this per-call batch on: measured on one MI355X (profiles/r02_xattn_batch_rule.log), fused forward + backward
+# against the composition per sub-block: B = 32 +25..30 % slower, B = 64 +9..13 % slower, B = 128 8..12 % faster, B = 256
+# 11..12 % faster -- the per-sample products of the absorbed form need the batch to fill the chip
+XATTN_TRAIN_MIN_BATCH = int(os.environ.get("M3AE_XATTN_TRAIN_MIN_BATCH", 96))
 
 
 def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):

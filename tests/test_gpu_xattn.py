@@ -188,3 +188,25 @@ def test_fused_cross_attention_backward_matches_the_composition(stream, I, pdrop
             assert gf[n].abs().max().item() <= 0.05 * scale and gu[n].abs().max().item() <= 0.05 * scale, n
             continue
         assert rel(gf[n], gu[n]) < tol, (n, rel(gf[n], gu[n]))
+
+
+def test_fused_training_path_batch_rule():
+    """Training takes the fused sub-block from ops.XATTN_TRAIN_MIN_BATCH samples per call on (default 96: measured slower than
+    the composition at 32 / 64, faster at 128 / 256, profiles/r02_xattn_batch_rule.log); forward-only calls always take it."""
+    from m3ae_amd.modules.bert_model import BertCrossLayer
+    layer = BertCrossLayer(D, H, 4 * D, drop_rate=0.0)
+    cfg = dict(learning_rate=1e-3, weight_decay=0.01, lr_multiplier_head=1, lr_multiplier_multi_modal=1)
+    ParamStore(layer, cfg, "cuda", torch.bfloat16, weight_units=layer.weight_units)
+    old = ops.XATTN_TRAIN_MIN_BATCH
+    try:
+        ops.XATTN_TRAIN_MIN_BATCH = 96
+        for B, want in ((4, False), (96, True)):
+            xt = torch.randn(B, 32, D, device="cuda").to(torch.bfloat16).requires_grad_(True)
+            xi = torch.randn(B, 145, D, device="cuda").to(torch.bfloat16)
+            layer(xt, xi, None, None)
+            assert layer._bp.fused_cross is want, (B, layer._bp.fused_cross)
+            with torch.no_grad():
+                layer(xt, xi, None, None)
+            assert layer._bp.fused_cross is True
+    finally:
+        ops.XATTN_TRAIN_MIN_BATCH = old
