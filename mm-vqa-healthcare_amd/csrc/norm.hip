@@ -114,6 +114,86 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
     }
 }
 
+// Row-PAIR form of the forward for bf16 rows of D % 256 == 0 elements (plain LayerNorm: no fused activation, not RMS): a
+// wave owns two consecutive rows = NP = D / 256 pieces of 16 B per lane (one contiguous stretch of 2 D elements), so every
+// global access is 16 B per lane instead of 8 (the one-row form's 4-element chunks: 4.2 TB/s at 147712 x 768) and the four
+// wave reductions of the pair cost what the one-row form spends on two rows.  Piece p = lane + 64 c of the pair: row p / (D / 8),
+// elements 8 (p % (D / 8)) .. + 7.
+template <int NP>
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+                                                          float* mean_o, float* rstd_o, int64_t M, float eps) {
+    constexpr int D = NP * 256, PPR = D / 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t npair = (M + 1) >> 1;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int sel[NP], col[NP];   // row of the pair (0 / 1) and first element of each of the lane's pieces
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int p = lane + 64 * c;
+        sel[c] = p >= PPR;
+        col[c] = (p - sel[c] * PPR) * 8;
+    }
+    u32x4 raw[NP];
+    auto load = [&](int64_t pair) {
+        const bf16_t* base = x + pair * 2 * D;
+        const bool two = pair * 2 + 1 < M;
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+            raw[c] = (two || !sel[c]) ? *(const u32x4*)(base + (lane + 64 * c) * 8) : (u32x4){0u, 0u, 0u, 0u};
+    };
+    if (pr < npair) load(pr);
+    for (; pr < npair; pr += stride) {
+        float v[NP][8];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[c][2 * q] = __uint_as_float(raw[c][q] << 16);
+                v[c][2 * q + 1] = __uint_as_float(raw[c][q] & 0xffff0000u);
+                t += v[c][2 * q] + v[c][2 * q + 1];
+            }
+            if (sel[c]) s1 += t; else s0 += t;
+        }
+        const int64_t cur = pr;
+        if (pr + stride < npair) load(pr + stride);
+        const float m0 = wave_sum(s0) / (float)D, m1 = wave_sum(s1) / (float)D;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const float mu = sel[c] ? m1 : m0;
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dlt = v[c][e] - mu; t += dlt * dlt; }
+            if (sel[c]) q1 += t; else q0 += t;
+        }
+        const float r0 = 1.0f / sqrtf(wave_sum(q0) / (float)D + eps), r1 = 1.0f / sqrtf(wave_sum(q1) / (float)D + eps);
+        const bool two = cur * 2 + 1 < M;
+        if (lane == 0) {
+            if (mean_o) { mean_o[cur * 2] = m0; if (two) mean_o[cur * 2 + 1] = m1; }
+            if (rstd_o) { rstd_o[cur * 2] = r0; if (two) rstd_o[cur * 2 + 1] = r1; }
+        }
+        bf16_t* yb = y + cur * 2 * D;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            if (!two && sel[c]) continue;
+            const float mu = sel[c] ? m1 : m0, rs = sel[c] ? r1 : r0;
+            const f32x4 g0 = *(const f32x4*)(gamma + col[c]), g1 = *(const f32x4*)(gamma + col[c] + 4);
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+            if (beta) { b0 = *(const f32x4*)(beta + col[c]); b1 = *(const f32x4*)(beta + col[c] + 4); }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[c][e] - mu) * rs * g0[e] + b0[e];
+                o[4 + e] = (v[c][4 + e] - mu) * rs * g1[e] + b1[e];
+            }
+            *(u32x4*)(yb + (lane + 64 * c) * 8) = (u32x4){pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+        }
+    }
+}
+
 template <typename T, int CPL, bool ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* beta,
                                                      const float* mean_i, const float* rstd_i, T* dx, const T* dx_add,
@@ -323,12 +403,29 @@ int launch_bwd(const void* dy, const void* x, const float* g, const float* b, co
 
 }  // namespace
 
+template <int NP>
+int launch_fwd_pair(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int64_t M, float eps,
+                    hipStream_t s) {
+    static const int cap = resident_blocks(ln_fwd_pair_kernel<NP>, 0);
+    const int64_t want = cdiv((M + 1) / 2, 4);
+    hipLaunchKernelGGL((ln_fwd_pair_kernel<NP>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, (const bf16_t*)x, g, b,
+                       (bf16_t*)y, mean, rstd, M, eps);
+    return hip_launch_status();
+}
+
 extern "C" int m3ae_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                   float* rstd, int64_t M, int64_t D, float eps, int dtype, int act, int rms,
                                   void* stream) {
     if (!x || !gamma || !y || M <= 0 || D <= 0) return M3AE_ERR_ARG;
     if (D % 4 != 0 || D > 4096) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    static const bool pair_off = getenv("M3AE_LN_PAIR_OFF") != nullptr;   // diagnostic A / B only (tools/ln_bench.py)
+    if (dtype == M3AE_BF16 && act == M3AE_ACT_NONE && !rms && M >= 1024 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 &&
+        ((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0 && !pair_off) {
+        if (D == 512) return launch_fwd_pair<2>(x, gamma, beta, y, mean, rstd, M, eps, s);
+        if (D == 768) return launch_fwd_pair<3>(x, gamma, beta, y, mean, rstd, M, eps, s);
+        if (D == 1024) return launch_fwd_pair<4>(x, gamma, beta, y, mean, rstd, M, eps, s);
+    }
     if (dtype == M3AE_F32) DISPATCH_CPL(launch_fwd, float, x, gamma, beta, y, mean, rstd, M, (int)D, eps, act, rms, s);
     if (dtype == M3AE_BF16) DISPATCH_CPL(launch_fwd, bf16_t, x, gamma, beta, y, mean, rstd, M, (int)D, eps, act, rms, s);
     return M3AE_ERR_UNSUPPORTED;
