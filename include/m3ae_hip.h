@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define M3AE_ABI_VERSION 1
+/* 2: m3ae_gemm_desc grew `preact_grad` and `launch_flags` (round 2), m3ae_xattn_desc grew `launch_flags` and dir 1 takes
+ *    probs == NULL (forward-only calls); m3ae_desc_sizes() lets a binding check its struct layouts at load time. */
+#define M3AE_ABI_VERSION 2
 
 enum { M3AE_F32 = 0, M3AE_BF16 = 1 };
 enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TANH = 3, M3AE_ACT_RELU = 4,
@@ -32,6 +34,9 @@ enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TA
 enum { M3AE_ERR_ARG = -1, M3AE_ERR_UNSUPPORTED = -2, M3AE_ERR_ALIGN = -3, M3AE_ERR_WORKSPACE = -4 };
 
 int m3ae_abi_version(void);
+/* sizeof(m3ae_gemm_desc), sizeof(m3ae_attn_desc), sizeof(m3ae_xattn_desc) as this library was compiled: a binding compares
+ * them with its own struct definitions before the first call (a descriptor that is too short is read past its end). */
+void m3ae_desc_sizes(int64_t out3[3]);
 /* name of the kernel family the last m3ae_gemm call on this thread dispatched to ("mfma_nt", "mfma_tn", "generic") */
 const char* m3ae_last_gemm_path(void);
 
@@ -81,6 +86,14 @@ typedef struct {
                             * hold CUs; a persistent workgroup that finds none starts after another has walked its list) */
 } m3ae_gemm_desc;
 enum { M3AE_GEMM_NO_PERSISTENT = 1 };
+/* Diagnostic selectors in launch_flags (0 in the product path = kernel chosen by shape): tests pin the kernel variants
+ * per call to compare them bit for bit, tools time them against each other.  The library keeps no tuning state.
+ *   NT variant v: 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its persistent form;
+ *   TN (wgrad) variant v: 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong;
+ *   column-tile group width g (1..12) of the ping-pong kernels' tile order. */
+#define M3AE_GEMM_NT_VARIANT(v) ((((v) + 1) & 0xf) << 8)
+#define M3AE_GEMM_TN_VARIANT(v) ((((v) + 1) & 0xf) << 12)
+#define M3AE_GEMM_COL_GROUP(g) (((g) & 0xf) << 16)
 int m3ae_gemm(const m3ae_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -177,8 +190,16 @@ typedef struct {
     void* ws_dctx;                /* dir 0: [B*Lq, D]                gradient of ctx */
     float* ws_vec;                /* fp32 [3 * B * H * 32] */
     float* ws_ln;                 /* fp32 [2 * m3ae_layernorm_bwd_blocks(B*Lq) * D] */
+    int32_t launch_flags;         /* M3AE_XATTN_*: per-call launch policy (the library keeps no state) */
 } m3ae_xattn_desc;
-int m3ae_xattn_supported(const m3ae_xattn_desc* d);   /* 1 if the fused kernels cover these shapes */
+enum { M3AE_XATTN_NO_PERSISTENT = 1,  /* the internal m3ae_gemm calls never take the persistent NT kernel (callers that run
+                                       * collectives next to the step: see m3ae_gemm_desc.launch_flags) */
+       M3AE_XATTN_LEGACY_CHAIN = 2    /* dir 1 forward: the round-2 chain (score GEMM + softmax epilogue, P through HBM, P V'
+                                       * GEMM) instead of the one-launch kernel of csrc/xflash.hip -- A/B measurements only */ };
+/* dir 1 (image queries): Lk = 32 or 64 text keys, any Lq; probs / probs_drop may be NULL in a forward-only call (the scores and
+ * probabilities then never leave the chip).  dir 0 (text queries): Lq = 32, Lk <= 640. */
+int m3ae_xattn_supported(const m3ae_xattn_desc* d);   /* 1 if the fused forward covers these shapes */
+int m3ae_xattn_bwd_supported(const m3ae_xattn_desc* d);   /* 1 if m3ae_xattn_bwd does too (32 text tokens) */
 int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d);
 int m3ae_xattn_fwd(const m3ae_xattn_desc* d, void* stream);
 /* Backward of m3ae_xattn_fwd in the same absorbed form: two more per-sample products per direction (the gradient of the
@@ -301,16 +322,6 @@ int m3ae_mim_loss_fwd(const void* x, const float* target, const float* mask, flo
                       int64_t D, int dtype, void* stream);
 int m3ae_mim_loss_bwd(const void* x, const float* target, const float* mask, const float* acc, const float* gout, void* dx,
                       int64_t B, int64_t L, int64_t D, int dtype, void* stream);
-
-/* DIAGNOSTIC knobs for A/B measurements of the GEMM kernels (tools/, tests): process-global, not part of the data path
- * contract -- the product path (m3ae_amd/) never calls this; launch policy that callers need is per call
- * (m3ae_gemm_desc.launch_flags).
- * key 0: NT GEMM kernel (-1 = auto by shape; 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its
- *        persistent form);
- * key 1: TN (wgrad) kernel (-1 = auto by shape; 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong);
- * key 6: 1 (default) = the auto path may use the persistent NT kernel; 0 = never (data-parallel runs: RCCL kernels
- *        hold CUs concurrently, see gemm_mfma.hip). */
-int m3ae_set_tuning(int key, int value);
 
 /* self-test of hardware idioms the kernels rely on (MFMA fragment maps, ds_read_b64_tr_b16, accumulator-as-
  * operand k-order).  out: int32[8 + 256] device buffer (tail = scratch), out[0] = number of mismatches. */

@@ -49,6 +49,7 @@ struct MfmaArgs {
     int64_t k_chunk;  // TN only: reduction rows per split (multiple of BK)
     int col_group;      // ping-pong NT kernels: column tiles per group of the tile order (nt_tile_coords)
     int no_persist;     // desc.launch_flags & M3AE_GEMM_NO_PERSISTENT
+    int nt_variant;     // desc.launch_flags selector (-1: by shape)
 };
 
 // Tile order inside the (XCD-contiguous) id range: column tiles in groups of GC, row-major inside a group.  An XCD then
@@ -481,21 +482,13 @@ int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int g_tn_variant = getenv("M3AE_TN_VARIANT") ? atoi(getenv("M3AE_TN_VARIANT")) : -1;
-static int g_nt_variant = getenv("M3AE_NT_VARIANT") ? atoi(getenv("M3AE_NT_VARIANT")) : -1;  // 0: 128x128, 2 stages (2 workgroups/CU); 1: 256x128, 3 stages (8 waves, 1 workgroup/CU)
-// persistent form of the ping-pong kernel (static tile lists, one workgroup per CU): OFF for data-parallel runs
-// (m3ae_set_tuning key 6, set by ddp.FlatGradReducer) -- when RCCL's kernels hold some CUs the persistent workgroups
-// that found no CU only start after others have walked their whole tile list (the kernel's time doubles); the
-// one-tile-per-workgroup launch just runs on the CUs that are free
-static int g_nt_persist = getenv("M3AE_NT_PERSIST") ? atoi(getenv("M3AE_NT_PERSIST")) : 1;
-static int g_nt_col_group = 0;   // 0: by shape (launch_nt)
-extern "C" int m3ae_set_tuning(int key, int value) {
-    if (key == 0) { g_nt_variant = value; return 0; }
-    if (key == 6) { g_nt_persist = value; return 0; }
-    if (key == 7) { g_nt_col_group = value; return 0; }
-    if (key == 1) { g_tn_variant = value; return 0; }
-    return M3AE_ERR_ARG;
-}
+// Kernel selection is by shape (the "auto" rules below).  A caller may pin a variant PER CALL through the selector fields of
+// m3ae_gemm_desc.launch_flags (M3AE_GEMM_NT_VARIANT / _TN_VARIANT / _COL_GROUP: tests compare the variants bit for bit, tools
+// time them against each other); the library keeps no tuning state and reads no environment variable.
+// The persistent form of the ping-pong kernel (static tile lists, one workgroup per CU) is never taken under
+// M3AE_GEMM_NO_PERSISTENT (data-parallel runs): when RCCL's kernels hold some CUs the persistent workgroups that found no CU only
+// start after others have walked their whole tile list (the kernel's time doubles); the one-tile-per-workgroup launch just runs
+// on the CUs that are free.
 
 template <int BM_, int BN_, int BKT, int NST, int WM, int EPI>
 static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
@@ -816,7 +809,7 @@ static int launch_nt_pp_persistent(const MfmaArgs& a, hipStream_t s) {
     return hip_launch_status();
 }
 
-// variants (m3ae_set_tuning key 0):
+// variants (launch_flags: M3AE_GEMM_NT_VARIANT(v)):
 //   0: 128x128 tile, BK 64, 2 stages, 4 waves x (64x64)   -- 64 KiB LDS, 2 workgroups / CU (small / few-tile shapes)
 //   4: 256x256 tile, BK 64, 2 stages, 8 waves x (128x64)  -- 128 KiB LDS, 1 workgroup / CU (the ping-pong kernel's
 //      bit-exact reference in tools/gemm_race.py)
@@ -832,6 +825,7 @@ static int launch_nt_pp_persistent(const MfmaArgs& a, hipStream_t s) {
 // pipe as busy as the two staggered wave rows do.
 template <int EPI>
 static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
+    const int g_nt_variant = a.nt_variant;
     if (g_nt_variant < 0) {  // auto (default): measured on MI355X, profiles/r01_gemm_shapes.log
         // 256 x 256 ping-pong kernel (one workgroup per CU, 256 slots) or 128 x 128 kernel (two per CU, 512 slots)?  What
         // decides is how full the last round of tiles is: efficiency = tiles / (rounds * slots).  The ping-pong kernel is
@@ -844,7 +838,7 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const double eff128 = (double)t128 / (double)(cdiv(t128, 512) * 512);
         const bool big = a.M > 128 && a.N > 128 && eff256 >= 0.88 * eff128;
         const bool persist_ok = t256 >= 512;   // the persistent form pays from two full rounds on (+1..3 %)
-        if (big && persist_ok && g_nt_persist && !a.no_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
+        if (big && persist_ok && !a.no_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
@@ -870,11 +864,13 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     {   // column tiles per group of the ping-pong kernels' tile order: all of them up to 9 (N <= 2304: B <= 3.4 MiB at
         // K = 768), else 6 -- measured against 3 / 4 / 12 on the path's shapes (profiles/r01_nt_col_group.log: -3..5 %)
         const int tiles_n = (int)((d.N + 255) / 256);
+        const int g_nt_col_group = (d.launch_flags >> 16) & 0xf;
         a.col_group = g_nt_col_group > 0 ? g_nt_col_group : (tiles_n <= 9 ? tiles_n : 6);
     }
     a.has_drop = d.dropout_p > 0.f;
     a.drop = make_drop(d.dropout_p, d.dropout_seed);
     a.no_persist = (d.launch_flags & M3AE_GEMM_NO_PERSISTENT) ? 1 : 0;
+    a.nt_variant = ((d.launch_flags >> 8) & 0xf) - 1;
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
     if (!has_dact && d.act == M3AE_ACT_RELU) return launch_nt_v<EPI_RELU>(a, s);                       // dropout allowed
@@ -1111,7 +1107,7 @@ static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
     const int64_t tiles = (d.M / BM_) * (d.N / BN_);
     const int64_t ksteps = cdiv(d.K, 64);
     const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
-    static const int64_t min_steps = getenv("M3AE_TN_MINSTEPS") ? atoi(getenv("M3AE_TN_MINSTEPS")) : 16;  // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us)
+    constexpr int64_t min_steps = 16;  // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us)
     int64_t splits = target / tiles;
     if (splits > ksteps / min_steps) splits = ksteps / min_steps;
     if (splits < 1) splits = 1;
@@ -1141,6 +1137,7 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     a.c_f32 = 1; a.alpha = d.alpha; a.accumulate = d.accumulate; a.a_rowsum = d.a_rowsum;
     // variant 1: 256x256 tile, 8 waves x (128x64): half the operand re-read traffic of the 128x128 tile
     const bool pp_ok = d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096;
+    const int g_tn_variant = ((d.launch_flags >> 12) & 0xf) - 1;
     if (g_tn_variant == 5 && pp_ok) return launch_tn_pp(a, d, s);
     if (g_tn_variant < 0) {  // auto (default), measured (profiles/r01_gemm_shapes.log): the ping-pong kernel wins on long
         // reductions (+2..10 % at 147712 rows) and, from 32768 rows, on the large outputs only

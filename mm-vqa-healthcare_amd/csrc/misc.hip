@@ -443,6 +443,9 @@ __global__ void scatter_add_rows_kernel(const T* d_out, const int64_t* idx, T* d
 }  // namespace
 
 extern "C" int m3ae_abi_version(void) { return M3AE_ABI_VERSION; }
+extern "C" void m3ae_desc_sizes(int64_t out3[3]) {
+    out3[0] = (int64_t)sizeof(m3ae_gemm_desc); out3[1] = (int64_t)sizeof(m3ae_attn_desc); out3[2] = (int64_t)sizeof(m3ae_xattn_desc);
+}
 
 extern "C" int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
                            void* stream) {

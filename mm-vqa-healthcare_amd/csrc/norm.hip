@@ -419,7 +419,8 @@ extern "C" int m3ae_layernorm_fwd(const void* x, const float* gamma, const float
     if (!x || !gamma || !y || M <= 0 || D <= 0) return M3AE_ERR_ARG;
     if (D % 4 != 0 || D > 4096) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    static const bool pair_off = getenv("M3AE_LN_PAIR_OFF") != nullptr;   // diagnostic A / B only (tools/ln_bench.py)
+    const bool pair_off = (rms & 2) != 0;   // rms bit 1: diagnostic A / B of the row-pair kernel (tools/ln_bench.py)
+    rms &= 1;
     if (dtype == M3AE_BF16 && act == M3AE_ACT_NONE && !rms && M >= 1024 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 &&
         ((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0 && !pair_off) {
         if (D == 512) return launch_fwd_pair<2>(x, gamma, beta, y, mean, rstd, M, eps, s);

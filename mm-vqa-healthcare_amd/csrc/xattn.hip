@@ -22,7 +22,7 @@
 // structure of gemm_nt_pp_kernel (8 waves in two barrier-staggered groups, 32-deep chunks DMA-staged into an LDS ring,
 // counted vmcnt), with the tile shape, the operand forms (K-contiguous rows or reduction-strided [K][cols] read with
 // ds_read_b64_tr_b16) and the epilogue as template parameters.
-#include "mfma_tiles.h"
+#include "xattn_common.h"
 
 namespace {
 
@@ -62,59 +62,6 @@ struct XgArgs {
     int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
 };
 
-DEVINL int64_t map_row(int64_t r, int div, int mul) { return div ? (r / div) * (int64_t)mul + r % div : r; }
-
-// nt_stage (mfma_tiles.h) with a memory-row map
-template <int SEGS_PER_WAVE, int NWAVES>
-DEVINL void nt_stage_m(const bf16_t* G, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile, int wave, int lane,
-                       int div, int mul) {
-#pragma unroll
-    for (int q = 0; q < SEGS_PER_WAVE; ++q) {
-        const int seg = q * NWAVES + wave;
-        const int row = seg * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ nt_swz<32>(row);
-        int64_t grow = row0 + row;
-        grow = grow < nrows ? grow : nrows - 1;
-        glds16(G + map_row(grow, div, mul) * ld + k0 + chunk * 8, tile + seg * 1024);
-    }
-}
-
-// one 1-KiB piece (4 rows) of a [32 k-rows][128 cols] panel of a reduction-strided operand; piece = 0..7
-DEVINL void t_stage128(const bf16_t* G, int64_t ld, int r0, int r_end, int col0, int ncols, char* panel, int piece,
-                       int lane, int div = 0, int mul = 0) {
-    const int wave = piece;
-    const int row = wave * 4 + (lane >> 4);
-    const int chunk = (lane & 15) ^ tn_swz(row);
-    const int grow = r0 + row, col = col0 + chunk * 8;
-    const int64_t mrow = div ? ((int64_t)(grow / div) * mul + grow % div) : (int64_t)grow;
-    const void* src = (grow < r_end && col < ncols) ? (const void*)(G + mrow * ld + col)
-                                                    : (const void*)((const char*)g_m3ae_zero_page + (lane & 15) * 16);
-    glds16(src, panel + wave * 1024);
-}
-
-template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int G> DEVINL void wait_vm_chunks(int chunks) {   // chunks in {0, 1, 2}
-    if (chunks >= 2) wait_vm<2 * G>();
-    else if (chunks == 1) wait_vm<G>();
-    else wait_vm<0>();
-}
-
-DEVINL float quad16_max(float v) {   // over the 4 lanes l, l^16, l^32, l^48
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-DEVINL float quad16_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
-DEVINL void st_bf4(bf16_t* p, const float* x) { *(u32x2*)p = (u32x2){pack2bf(x[0], x[1]), pack2bf(x[2], x[3])}; }
-DEVINL void ld_bf4(const bf16_t* p, float* x) {
-    const u32x2 v = *(const u32x2*)p;
-    x[0] = __uint_as_float(v[0] << 16); x[1] = __uint_as_float(v[0] & 0xffff0000u);
-    x[2] = __uint_as_float(v[1] << 16); x[3] = __uint_as_float(v[1] & 0xffff0000u);
-}
-
-constexpr float LOG2E = 1.4426950408889634f;
 
 #ifdef M3AE_XG_TRACE   // diagnostic build only (tools/xg_trace.py): per-workgroup timeline stamps, never in the product build
 __device__ uint64_t g_xg_trace[8 * 16 * 4096];   // [launch slot][block][4 x 100-MHz ticks, 4 x shader clocks, 8 in-loop clocks]
@@ -176,7 +123,9 @@ template <int WN, class RowPtr> DEVINL void slab_store_bf16(const char* slab, in
 //   NLOAD == 0 (the 128 x 640 whole-row score tile: 160 accumulators per lane leave no room for a third wave per SIMD): the 8
 //   compute waves stage their own operands in gemm_nt_pp_kernel's two-phase schedule (B part of chunk c + NSLOT - 1 requested
 //   in phase 2c, A part in phase 2c + 1, chunk consumed in two halves of the row blocks).
-template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI>
+//   GEN = 0 (most launches): no memory-row maps and no second operand pair -- their address arithmetic (an integer division per
+//   staged piece) and branches compile out of the staging code, which sits in every chunk's read phase.
+template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI, int GEN>
 __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(XgArgs a) {
     constexpr int WAVES_N = 8 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
     constexpr int NST = NLOAD ? NLOAD : 8;   // waves that issue the LDS-DMA pieces
@@ -205,39 +154,41 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
     const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
     const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
     const int lw = NLOAD ? wave - 8 : wave;   // index among the staging waves
-    const bf16_t* A2 = a.A2 ? a.A2 + (int64_t)bi * a.a_sb : nullptr;
-    const bf16_t* B2 = a.B2 ? a.B2 + (int64_t)bi * a.b_sb : nullptr;
-    const int k1_rows = a.k_switch ? a.k_switch * 32 : a.K;     // reduction rows of the first pair (T-form bound)
+    const bf16_t* A2 = (GEN && a.A2) ? a.A2 + (int64_t)bi * a.a_sb : nullptr;
+    const bf16_t* B2 = (GEN && a.B2) ? a.B2 + (int64_t)bi * a.b_sb : nullptr;
+    const int k_switch = GEN ? a.k_switch : 0;
+    const int a_div = GEN ? a.a_div : 0, a_mul = GEN ? a.a_mul : 0, b_div = GEN ? a.b_div : 0, b_mul = GEN ? a.b_mul : 0;
+    const int k1_rows = k_switch ? k_switch * 32 : a.K;     // reduction rows of the first pair (T-form bound)
     auto stage_b = [&](int c, char* slot) {
         int cc = c + c_first;
-        const bool second = a.k_switch && cc >= a.k_switch;
+        const bool second = k_switch && cc >= k_switch;
         const bf16_t* Bp = second ? B2 : B;
-        const int kend = second ? a.K - a.k_switch * 32 : k1_rows;
-        if (second) cc -= a.k_switch;
-        if constexpr (BFORM == FORM_K) nt_stage_m<GB, NST>(Bp, a.ldb, n0, a.b_rows ? a.b_rows : a.N, (int64_t)cc * 32, slot + A_BYTES, lw, lane, a.b_div, a.b_mul);
+        const int kend = second ? a.K - k_switch * 32 : k1_rows;
+        if (second) cc -= k_switch;
+        if constexpr (BFORM == FORM_K) nt_stage_m<GB, NST>(Bp, a.ldb, n0, a.b_rows ? a.b_rows : a.N, (int64_t)cc * 32, slot + A_BYTES, lw, lane, b_div, b_mul);
         else {
 #pragma unroll
             for (int p = 0; p < BN / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(Bp, a.ldb, cc * 32, kend, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane, a.b_div, a.b_mul);
+                    t_stage128(Bp, a.ldb, cc * 32, kend, n0 + p * 128, a.N, slot + A_BYTES + p * 8192, lw + NST * h, lane, b_div, b_mul);
         }
     };
     auto stage_a = [&](int c, char* slot) {
         int cc = c + c_first;
-        const bool second = a.k_switch && cc >= a.k_switch;
+        const bool second = k_switch && cc >= k_switch;
         const bf16_t* Ap = second ? A2 : A;
-        const int kend = second ? a.K - a.k_switch * 32 : k1_rows;
-        if (second) cc -= a.k_switch;
+        const int kend = second ? a.K - k_switch * 32 : k1_rows;
+        if (second) cc -= k_switch;
         if constexpr (AFORM == FORM_K) {
-            if constexpr (GA >= 1) nt_stage_m<GA, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
-            else if (lw < BM / 16) nt_stage_m<1, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a.a_div, a.a_mul);
+            if constexpr (GA >= 1) nt_stage_m<GA, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a_div, a_mul);
+            else if (lw < BM / 16) nt_stage_m<1, NST>(Ap, a.lda, m0, a.M, (int64_t)cc * 32, slot, lw, lane, a_div, a_mul);
         } else {
 #pragma unroll
             for (int p = 0; p < BM / 128; ++p)
 #pragma unroll
                 for (int h = 0; h < 8 / NST; ++h)
-                    t_stage128(Ap, a.lda, cc * 32, kend, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane, a.a_div, a.a_mul);
+                    t_stage128(Ap, a.lda, cc * 32, kend, m0 + p * 128, a.M, slot + p * 8192, lw + NST * h, lane, a_div, a_mul);
         }
     };
     auto stage = [&](int c, char* slot) { stage_b(c, slot); stage_a(c, slot); };
@@ -788,12 +739,13 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
 #ifdef M3AE_XG_TRACE
 int g_trace_next = 0;
 #endif
-template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI>
+template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI, int GEN = 0>
 int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
+    if (!GEN && (a.a_div || a.b_div || a.k_switch || a.A2 || a.B2)) return M3AE_ERR_ARG;   // needs the GEN = 1 instantiation
     constexpr int lds = NSLOT * (BM + BN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI, GEN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -803,7 +755,7 @@ int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
     a.trace_slot = g_trace_next++ & 7;
 #endif
     const unsigned grid = (unsigned)(nbatch * a.tiles_m * a.tiles_n * (a.ksplit > 1 ? a.ksplit : 1));
-    hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI>), dim3(grid), dim3(NLOAD ? 768 : 512), lds, s, a);
+    hipLaunchKernelGGL((xg_kernel<BM, BN, WAVES_M, NSLOT, NLOAD, AFORM, BFORM, EPI, GEN>), dim3(grid), dim3(NLOAD ? 768 : 512), lds, s, a);
     return hip_launch_status();
 }
 
@@ -933,7 +885,17 @@ extern "C" int m3ae_xattn_supported(const m3ae_xattn_desc* d) {
     const int64_t T = d->dir == 0 ? d->Lq : d->Lk, I = d->dir == 0 ? d->Lk : d->Lq;
     if (d->H <= 0 || d->D % d->H != 0) return 0;
     const int64_t dh = d->D / d->H;
-    return (T == 32 && I >= 1 && I <= 640 && dh % 32 == 0 && d->D % 128 == 0) ? 1 : 0;
+    if (I < 1 || dh % 32 != 0 || d->D % 128 != 0) return 0;
+    if (d->dir == 0) return (T == 32 && I <= 640) ? 1 : 0;   // text queries: the whole-row score tile covers 640 keys
+    // image queries (xflash.hip): 32 text keys (fine-tuning) or 64 (pre-training), any number of image tokens
+    if (d->launch_flags & M3AE_XATTN_LEGACY_CHAIN) return (T == 32 && I <= 640) ? 1 : 0;
+    return ((T == 32 || T == 64) && d->H * T == (T == 32 ? 384 : 768) && d->D % 256 == 0) ? 1 : 0;
+}
+
+extern "C" int m3ae_xattn_bwd_supported(const m3ae_xattn_desc* d) {
+    if (!m3ae_xattn_supported(d)) return 0;
+    const int64_t T = d->dir == 0 ? d->Lq : d->Lk;
+    return T == 32 ? 1 : 0;   // the backward's softmax epilogues sum over 32-column groups
 }
 
 extern "C" int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d) {   // row stride (elements) of `probs` / `probs_drop`
@@ -950,13 +912,15 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
     const int Lq = (int)d.Lq, Lk = (int)d.Lk;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool drop = d.dropout_p > 0.f;
-    if (!d.x || !d.y || !d.proj || !d.prime || !d.probs || !d.s || !d.out || (drop && !d.probs_drop)) return M3AE_ERR_ARG;
+    if (!d.x || !d.y || !d.proj || !d.prime || !d.s || !d.out) return M3AE_ERR_ARG;
+    if (d.dir == 0 && (!d.probs || (drop && !d.probs_drop))) return M3AE_ERR_ARG;
 
     m3ae_gemm_desc g{};
     g.batch1 = g.batch2 = 1;
     g.dtype_a = g.dtype_b = g.dtype_c = M3AE_BF16;
     g.alpha = 1.0f;
     g.a_sk = g.b_sk = g.c_sn = 1;
+    g.launch_flags = (d.launch_flags & M3AE_XATTN_NO_PERSISTENT) ? M3AE_GEMM_NO_PERSISTENT : 0;
 
     if (d.dir == 0) {
         const int T = Lq, I = Lk, R = T * H;
@@ -1046,31 +1010,46 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
                                (int64_t)2 * D, d.bq, d.key_mask, d.colbias, B, T, H, dh, scale);
             XCHK(hip_launch_status());
         }
-        {   // P = softmax over each head's 32 keys of (x K'^T + c)
-            XgArgs a{};
-            a.A = (const bf16_t*)d.x; a.lda = D; a.a_sb = (int64_t)I * D;
-            a.B = Kp; a.ldb = D; a.b_sb = (int64_t)R * D;
-            a.M = I; a.N = R; a.K = D;
-            a.C = (bf16_t*)d.probs; a.ldc = R; a.c_sb = (int64_t)I * R;
-            a.C2 = drop ? (bf16_t*)d.probs_drop : nullptr;
-            a.alpha = 1.0f;
-            a.colbias = d.colbias; a.cb_sb = R;
-            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
-            a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
-        }
-        {   // s = dropout(drop(P) V' + bo) + x
-            XgArgs a{};
-            a.A = (const bf16_t*)(drop ? d.probs_drop : d.probs); a.lda = R; a.a_sb = (int64_t)I * R;
-            a.B = Vp; a.ldb = D; a.b_sb = (int64_t)R * D;
-            a.M = I; a.N = D; a.K = R;
-            a.C = (bf16_t*)d.s; a.ldc = D;
-            a.bias = d.bo;
-            a.residual = (const bf16_t*)d.x;
-            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
-            // (LayerNorm in this kernel's epilogue -- a 64 x 768 whole-row tile -- was built and measured: the 13-us epilogue of a
-            // tile that nothing overlaps costs what the separate 106-us LayerNorm pass costs, 310 vs 326 us: not kept)
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
+        if (!(d.launch_flags & M3AE_XATTN_LEGACY_CHAIN)) {
+            // ONE launch (csrc/xflash.hip): S = x K'^T, softmax + attention dropout in registers, drop(P) resident in LDS,
+            // s = dropout(drop(P) V' + bo) + x.  probs / probs_drop are written only when the caller passes them (training).
+            if (drop && d.probs && !d.probs_drop) return M3AE_ERR_ARG;
+            XfArgs f{};
+            f.X = (const bf16_t*)d.x; f.Kp = Kp; f.Vp = Vp; f.colbias = d.colbias; f.bo = d.bo;
+            f.S = (bf16_t*)d.s; f.P = (bf16_t*)d.probs; f.Pd = drop ? (bf16_t*)d.probs_drop : nullptr;
+            f.B = B; f.I = I; f.D = D; f.H = H;
+            f.has_drop = drop; f.drop_a = make_drop(d.dropout_p, d.seed_attn); f.drop_h = make_drop(d.dropout_p, d.seed_hidden);
+            f.drop_ld = (int)drop_ld(T);
+            // (LayerNorm inside this launch -- single-pass statistics in the pass epilogues, a cross-wave exchange, a normalise
+            // pass over the tile's own stores -- was built and measured in round 3: kernel 340 -> 487 us against 89 us for the
+            // separate pass below: the re-reads wait for the tile's stores to drain and nothing else runs on the CU meanwhile)
+            XCHK(m3ae_xflash_dir1(f, T, s));
+        } else {
+            if (T != 32 || !d.probs || (drop && !d.probs_drop)) return M3AE_ERR_UNSUPPORTED;
+            {   // P = softmax over each head's 32 keys of (x K'^T + c)
+                XgArgs a{};
+                a.A = (const bf16_t*)d.x; a.lda = D; a.a_sb = (int64_t)I * D;
+                a.B = Kp; a.ldb = D; a.b_sb = (int64_t)R * D;
+                a.M = I; a.N = R; a.K = D;
+                a.C = (bf16_t*)d.probs; a.ldc = R; a.c_sb = (int64_t)I * R;
+                a.C2 = drop ? (bf16_t*)d.probs_drop : nullptr;
+                a.alpha = 1.0f;
+                a.colbias = d.colbias; a.cb_sb = R;
+                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+                a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
+                XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
+            }
+            {   // s = dropout(drop(P) V' + bo) + x
+                XgArgs a{};
+                a.A = (const bf16_t*)(drop ? d.probs_drop : d.probs); a.lda = R; a.a_sb = (int64_t)I * R;
+                a.B = Vp; a.ldb = D; a.b_sb = (int64_t)R * D;
+                a.M = I; a.N = D; a.K = R;
+                a.C = (bf16_t*)d.s; a.ldc = D;
+                a.bias = d.bo;
+                a.residual = (const bf16_t*)d.x;
+                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
+                XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
+            }
         }
     }
     // out = LayerNorm(s)                                                          (bert_model.py:363)
@@ -1090,7 +1069,7 @@ void pick_split(XgArgs& a, int nchunks, int tiles) {
 }  // namespace
 
 extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
-    if (!dp || !m3ae_xattn_supported(dp)) return M3AE_ERR_UNSUPPORTED;
+    if (!dp || !m3ae_xattn_bwd_supported(dp)) return M3AE_ERR_UNSUPPORTED;
     const m3ae_xattn_desc& d = *dp;
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)d.B, H = (int)d.H, D = (int)d.D, dh = D / H;
@@ -1117,6 +1096,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
     g.batch1 = g.batch2 = 1;
     g.dtype_a = g.dtype_b = M3AE_BF16;
     g.alpha = 1.0f;
+    g.launch_flags = (d.launch_flags & M3AE_XATTN_NO_PERSISTENT) ? M3AE_GEMM_NO_PERSISTENT : 0;
 
     if (d.dir == 1) {
         const int I = Lq, T = Lk, R = H * T;
@@ -1169,13 +1149,13 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
             a.C = dkv; a.ldc = 2 * D; a.c_sb = dh; a.alpha = scale;
             a.bias = d.bq; a.bias_sb = dh;
             a.rowscale = dcb; a.rs_sm = 1; a.rs_sb = T; a.rs_div = T; a.rs_mul = R;
-            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE, 1>(a, H, s)));
             XgArgs v{};
             v.A = dVp; v.lda = D; v.a_sb = (int64_t)T * D; v.a_div = T; v.a_mul = R;
             v.B = (const bf16_t*)d.wo_t; v.ldb = D; v.b_sb = (int64_t)dh * D;
             v.M = B * T; v.N = dh; v.K = D;
             v.C = dkv + D; v.ldc = 2 * D; v.c_sb = dh; v.alpha = 1.0f;
-            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE>(v, H, s)));
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_K, FORM_K, XE_STORE, 1>(v, H, s)));
         }
         {   // dWq[h] += scale k_h^T dK'_h ; dWo[:, h] += dV'_h^T v_h      (reductions over the B*T text rows: split-K atomics)
             XgArgs a{};
@@ -1184,14 +1164,14 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
             a.M = dh; a.N = D; a.K = B * T;
             a.Cf = d.g_wq; a.ldc = D; a.c_sb = (int64_t)dh * D; a.alpha = scale;
             pick_split(a, (B * T + 31) / 32, H * ((D + 383) / 384));
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(a, H, s)));
+            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_ATOMIC, 1>(a, H, s)));
             XgArgs o{};
             o.A = dVp; o.lda = D; o.a_sb = (int64_t)T * D; o.a_div = T; o.a_mul = R;
             o.B = (const bf16_t*)d.proj + D; o.ldb = 2 * D; o.b_sb = dh;
             o.M = D; o.N = dh; o.K = B * T;
             o.Cf = d.g_wo; o.ldc = D; o.c_sb = dh; o.alpha = 1.0f;
             pick_split(o, (B * T + 31) / 32, H * ((D + 383) / 384));
-            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_T, FORM_T, XE_ATOMIC>(o, H, s)));
+            XCHK((launch_xg<384, 128, 4, 4, 4, FORM_T, FORM_T, XE_ATOMIC, 1>(o, H, s)));
         }
         hipLaunchKernelGGL(xattn_headvec_kernel, dim3(H, (B * T + 255) / 256), dim3(256), 0, s, (const float*)dcb,
                            (const bf16_t*)d.proj, (int64_t)2 * D, d.g_bq, B * T, T, R, 1, T, dh);
@@ -1280,7 +1260,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
         a.M = I; a.N = D; a.K = 2 * R;          // one pass over both reductions: chunks 0 .. R/32 - 1 from (drop(P), dZ), then (dS, Q')
         a.A2 = dS; a.B2 = (const bf16_t*)d.prime; a.k_switch = R / 32;
         a.C = (bf16_t*)d.dy; a.ldc = D; a.c_sb = (int64_t)I * D; a.alpha = 1.0f;
-        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE>(a, B, s)));
+        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_T, FORM_T, XE_STORE, 1>(a, B, s)));
     }
     {   // per head: dq_h = scale dQ'_h Wk_h^T ; dWk[h] += scale q_h^T dQ'_h
         XgArgs a{};

@@ -50,18 +50,25 @@ class XattnDesc(C.Structure):
         ("d_out", vp), ("dx", vp), ("dy", vp),
         ("g_wq", vp), ("g_wkv", vp), ("g_wo", vp), ("g_bq", vp), ("g_bkv", vp), ("g_bo", vp), ("g_ln_g", vp), ("g_ln_b", vp),
         ("ws_ds", vp), ("ws_dsd", vp), ("ws_dscores", vp), ("ws_dprime", vp), ("ws_dproj", vp), ("ws_dz", vp), ("ws_dctx", vp),
-        ("ws_vec", vp), ("ws_ln", vp),
+        ("ws_vec", vp), ("ws_ln", vp), ("launch_flags", i32),
     ]
+
+
+GEMM_NO_PERSISTENT = 1                            # m3ae_gemm_desc.launch_flags
+XATTN_NO_PERSISTENT, XATTN_LEGACY_CHAIN = 1, 2    # m3ae_xattn_desc.launch_flags
+ABI_VERSION = 2
 
 
 _SIGS = {
     "m3ae_abi_version": (C.c_int, []),
+    "m3ae_desc_sizes": (None, [C.POINTER(i64)]),
     "m3ae_last_gemm_path": (C.c_char_p, []),
     "m3ae_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "m3ae_attn_workspace_bytes": (i64, [C.POINTER(AttnDesc), C.c_int]),
     "m3ae_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "m3ae_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "m3ae_xattn_supported": (C.c_int, [C.POINTER(XattnDesc)]),
+    "m3ae_xattn_bwd_supported": (C.c_int, [C.POINTER(XattnDesc)]),
     "m3ae_xattn_probs_ld": (i64, [C.POINTER(XattnDesc)]),
     "m3ae_xattn_fwd": (C.c_int, [C.POINTER(XattnDesc), vp]),
     "m3ae_xattn_bwd": (C.c_int, [C.POINTER(XattnDesc), vp]),
@@ -93,7 +100,6 @@ _SIGS = {
     "m3ae_mim_loss_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_mim_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_selftest": (C.c_int, [vp, vp]),
-    "m3ae_set_tuning": (C.c_int, [C.c_int, C.c_int]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -115,8 +121,13 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if l.m3ae_abi_version() != 1:
-            raise M3AEHipError("ABI version mismatch")
+        if l.m3ae_abi_version() != ABI_VERSION:
+            raise M3AEHipError(f"ABI version mismatch: library {l.m3ae_abi_version()}, binding {ABI_VERSION}")
+        sizes = (i64 * 3)()
+        l.m3ae_desc_sizes(sizes)
+        mine = (C.sizeof(GemmDesc), C.sizeof(AttnDesc), C.sizeof(XattnDesc))
+        if tuple(sizes) != mine:   # a descriptor that is too short would be read past its end
+            raise M3AEHipError(f"descriptor layout mismatch: library {tuple(sizes)}, binding {mine}")
         _lib = l
     return _lib
 

@@ -69,7 +69,7 @@ class BertAttention(nn.Module):
             P = self.block_params()
             h2, o2 = h.contiguous().view(B * L, D), other.contiguous().view(B * Lo, other.shape[2])
             if ops.xattn_supported(h2, L, o2, Lo, other_mask, P):
-                return ops.xattn_fwd(h2, B, L, o2, Lo, other_mask, P, pdrop)[0].view(B, L, D)
+                return ops.xattn_fwd(h2, B, L, o2, Lo, other_mask, P, pdrop, need_bwd=False)[0].view(B, L, D)
         da = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
         dh = (pdrop, ops.next_dropout_seed()) if pdrop > 0 else None
         if other is None:
@@ -156,6 +156,7 @@ class BertCrossLayer(nn.Module):
         # forward-only calls always take the fused cross-attention sub-block; training takes it with its fused backward
         self._bp.fused_cross = (not torch.is_grad_enabled()) or (ops.XATTN_TRAIN != "off" and
                                                                  hidden_states.shape[0] >= ops.XATTN_TRAIN_MIN_BATCH)
+        self._bp.cross.need_bwd = torch.is_grad_enabled()
         return ops.BertCrossLayerFn.apply(hidden_states, encoder_hidden_states, attention_mask, encoder_attention_mask,
                                           self._bp, *self._anchors)
 

@@ -23,6 +23,14 @@ SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
 # host-side launch policy, set by ddp.FlatGradReducer while collectives run next to backward (per-call flag in the GEMM
 # descriptor: the library itself keeps no state)
 NT_NO_PERSISTENT = False
+# diagnostic per-call kernel selectors (m3ae_gemm_desc.launch_flags; -1 / 0 = by shape): tests compare kernel variants bit for
+# bit, tools time them; the product path never sets them
+GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = -1, -1, 0
+
+
+def _gemm_flags():
+    return ((1 if NT_NO_PERSISTENT else 0) | (((GEMM_NT_VARIANT + 1) & 0xF) << 8) | (((GEMM_TN_VARIANT + 1) & 0xF) << 12)
+            | ((GEMM_COL_GROUP & 0xF) << 16))
 PROFILE = None  # when a list: every GEMM / attention launch is bracketed by HIP events on the launch stream
 
 
@@ -110,7 +118,7 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
             setattr(d, name, t.data_ptr())
     d.dact = dact
     d.preact_grad = int(preact_grad)
-    d.launch_flags = 1 if NT_NO_PERSISTENT else 0
+    d.launch_flags = _gemm_flags()
     d.force_generic = int(force_generic)
     if a_rowsum is not None:
         assert a_rowsum.dtype == torch.float32 and a_rowsum.numel() >= M and batch == (1, 1)
@@ -587,6 +595,8 @@ XATTN_TRAIN = os.environ.get("M3AE_XATTN_TRAIN", "auto")
 # against the composition per sub-block: B = 32 +25..30 % slower, B = 64 +9..13 % slower, B = 128 8..12 % faster, B = 256
 # 11..12 % faster -- the per-sample products of the absorbed form need the batch to fill the chip
 XATTN_TRAIN_MIN_BATCH = int(os.environ.get("M3AE_XATTN_TRAIN_MIN_BATCH", 96))
+# A/B measurements (tools/, tests): the round-2 dir-1 forward chain (P through HBM) instead of the one-launch kernel
+XATTN_LEGACY_CHAIN = False
 
 
 def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):
@@ -603,10 +613,14 @@ def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):
     d.ln_g, d.ln_b, d.ln_eps = P.ln.weight.data_ptr(), P.ln.bias.data_ptr(), P.ln.eps
     if pdrop > 0:
         d.dropout_p, d.seed_attn, d.seed_hidden = pdrop, seeds[0], seeds[1]
+    d.launch_flags = (_lib.XATTN_NO_PERSISTENT if NT_NO_PERSISTENT else 0) | (_lib.XATTN_LEGACY_CHAIN if XATTN_LEGACY_CHAIN else 0)
     return d
 
 
-def xattn_supported(h2, L, other2, Lo, mask, P):
+def xattn_supported(h2, L, other2, Lo, mask, P, backward=False):
+    """The fused sub-block covers these shapes (forward); backward=True: and m3ae_xattn_bwd does, and every projection
+    parameter is trainable (the fused backward accumulates all six gradients in place; a layer with frozen projections
+    whose input still needs a gradient takes the composition)."""
     if XATTN == "off" or h2.dtype != torch.bfloat16 or other2.shape[1] != h2.shape[1]:
         return False
     if getattr(P.w_q, "m3ae_t", None) is None or getattr(P.w_kv, "m3ae_t", None) is None or getattr(P.w_o, "m3ae_t", None) is None:
@@ -614,11 +628,17 @@ def xattn_supported(h2, L, other2, Lo, mask, P):
     d = XattnDesc()
     d.dir = 0 if L <= Lo else 1
     d.B, d.Lq, d.Lk, d.D, d.H = 1, L, Lo, h2.shape[1], P.heads
-    return bool(_lib.lib().m3ae_xattn_supported(C.byref(d)))
+    d.launch_flags = _lib.XATTN_LEGACY_CHAIN if XATTN_LEGACY_CHAIN else 0
+    if not backward:
+        return bool(_lib.lib().m3ae_xattn_supported(C.byref(d)))
+    if not all(p.requires_grad for p in (P.w_q, P.w_kv, P.w_o, P.b_q, P.b_kv, P.b_o)):
+        return False
+    return bool(_lib.lib().m3ae_xattn_bwd_supported(C.byref(d)))
 
 
-def xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
-    """BertAttention as crossattention (bert_model.py:480-488) through the fused kernels.  Returns (out, saved)."""
+def xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0, need_bwd=True):
+    """BertAttention as crossattention (bert_model.py:480-488) through the fused kernels.  Returns (out, saved).
+    need_bwd=False (forward-only call): the image-query direction keeps scores and probabilities on chip."""
     _need_cuda(h2)
     dev, D, H = h2.device, h2.shape[1], P.heads
     seeds = (next_dropout_seed(), next_dropout_seed()) if pdrop > 0 else None
@@ -640,9 +660,10 @@ def xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0):
         t["proj"] = e(B * Lo, 2 * D)
         t["prime"] = e(2, B, R, D)
         t["colbias"] = e(B, R, dt=torch.float32)
-        t["probs"] = e(B, L, R)
-        if pdrop > 0:
-            t["probs_drop"] = e(B, L, R)
+        if need_bwd or XATTN_LEGACY_CHAIN:
+            t["probs"] = e(B, L, R)
+            if pdrop > 0:
+                t["probs_drop"] = e(B, L, R)
     t["s"] = e(B * L, D)
     t["out"] = e(B * L, D)
     t["mean"] = e(B * L, dt=torch.float32)
@@ -701,8 +722,10 @@ def _attn_sub_fwd(h2, B, L, other2, Lo, mask, P, pdrop=0.0, fused_cross=False):
     pdrop > 0 (training): attention-probability dropout (:334) and hidden dropout on the output dense (:362)."""
     heads = P.heads
     D = h2.shape[1]
-    if other2 is not None and fused_cross and xattn_supported(h2, L, other2, Lo, mask, P):
-        return xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop)
+    if other2 is not None and fused_cross:
+        need_bwd = getattr(P, "need_bwd", True)
+        if xattn_supported(h2, L, other2, Lo, mask, P, backward=need_bwd):
+            return xattn_fwd(h2, B, L, other2, Lo, mask, P, pdrop, need_bwd=need_bwd)
     da = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     dh = (pdrop, next_dropout_seed()) if pdrop > 0 else None
     if other2 is None:

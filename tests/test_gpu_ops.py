@@ -56,7 +56,7 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
 def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
     from m3ae_amd import _lib
-    _lib.lib().m3ae_set_tuning(0, variant)
+    ops.GEMM_NT_VARIANT = variant
     for M, N, K in [(1, 128, 64), (127, 132, 192), (129, 260, 64), (300, 8, 3072), (1000, 3072, 768), (577, 768, 128),
                     (2308, 2304, 768)]:
         x, w = rnd(M, K, dtype=torch.bfloat16, seed=5), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=6)
@@ -65,7 +65,7 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
         y2, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32, force_generic=True)
         assert ops.last_gemm_path() == "generic"
         close(y1, y2, 1e-5, 1e-5, msg=f"{M}x{N}x{K}")
-    _lib.lib().m3ae_set_tuning(0, -1)
+    ops.GEMM_NT_VARIANT = -1
 
 
 @pytest.mark.parametrize("variant", [7, 8, -1])
@@ -81,7 +81,7 @@ def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant,
     b = rnd(N, seed=33)
     aux = rnd(M, N, dtype=torch.bfloat16, seed=34)
     pre = x.float() @ w.float().t()
-    L.m3ae_set_tuning(0, variant)
+    ops.GEMM_NT_VARIANT = variant
     try:
         y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         extra = None
@@ -110,7 +110,7 @@ def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant,
         assert ops.last_gemm_path() == "mfma_nt_pp"
         close(y, ref, 1e-2, 2e-2, msg=f"variant {variant} {kind}")
     finally:
-        L.m3ae_set_tuning(0, -1)
+        ops.GEMM_NT_VARIANT = -1
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (577 * 2, 768, 768), (1000, 2304, 768), (4616, 768, 3072), (37, 128, 256),
@@ -501,7 +501,7 @@ def test_gemm_wgrad_tn_pingpong_variant(M, N, K):
     """TN variant 5 (gemm_tn_pp_kernel: 256x256 tile, staggered wave rows) incl. ragged reduction tails and the fused
     bias gradient; repeated to screen the ring for races (every run must agree with the fp32 reference)."""
     from m3ae_amd import _lib
-    _lib.lib().m3ae_set_tuning(1, 5)
+    ops.GEMM_TN_VARIANT = 5
     try:
         dy, x = rnd(M, N, dtype=torch.bfloat16, seed=70), rnd(M, K, dtype=torch.bfloat16, seed=71)
         ref = dy.float().t() @ x.float()
@@ -514,7 +514,7 @@ def test_gemm_wgrad_tn_pingpong_variant(M, N, K):
             close(g, ref, 1e-4, 1e-3 * math.sqrt(M), msg=f"wgrad pp iter {it}")
             close(db, refb, 1e-4, 1e-3 * math.sqrt(M), msg=f"bias grad pp iter {it}")
     finally:
-        _lib.lib().m3ae_set_tuning(1, -1)
+        ops.GEMM_TN_VARIANT = -1
 
 
 def test_vocab_projection_padded_mfma_path_for_odd_vocabulary():
@@ -642,7 +642,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     outs = {}
     try:
         for v in (4, 7, 8):
-            L.m3ae_set_tuning(0, v)
+            ops.GEMM_NT_VARIANT = v
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             extra = None
             if kind == "plain":
@@ -661,7 +661,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
             if outs[4][1] is not None:
                 assert torch.equal(outs[v][1].view(torch.int16), outs[4][1].view(torch.int16)), (kind, v, "derivative")
     finally:
-        L.m3ae_set_tuning(0, -1)
+        ops.GEMM_NT_VARIANT = -1
 
 
 def test_mim_bookkeeping_kernels_match_the_reference_formulas():

@@ -118,17 +118,80 @@ def test_fused_cross_attention_dropout_uses_the_same_masks_as_the_unfused_path(d
     assert rms(f - ev) > 0.2 and rms(f - f2) > 0.2   # dropout really happened, and depends on the seed
 
 
-def test_fused_cross_attention_falls_back_on_uncovered_shapes():
+def test_fused_cross_attention_coverage_and_fallback():
+    """Image queries (csrc/xflash.hip) cover 32 and 64 text keys and any number of image tokens; text queries (the whole-row
+    score tile) 32 text tokens and <= 640 image tokens; everything else takes the composition."""
     att, _ = make(seed=6)
     P = att.block_params()
-    x = torch.randn(2 * 64, D, device="cuda").to(torch.bfloat16)      # 64 text tokens (pre-training): not covered
+    x = torch.randn(2 * 64, D, device="cuda").to(torch.bfloat16)      # 64 text tokens (pre-training, config.py:121-147)
     y = torch.randn(2 * 577, D, device="cuda").to(torch.bfloat16)
-    assert not ops.xattn_supported(x, 64, y, 577, None, P)
-    y2 = torch.randn(2 * 1025, D, device="cuda").to(torch.bfloat16)   # 512 px: 1025 image tokens
+    assert not ops.xattn_supported(x, 64, y, 577, None, P)            # text queries: not covered
+    assert ops.xattn_supported(y, 577, x, 64, None, P)                # image queries: covered (forward)
+    assert not ops.xattn_supported(y, 577, x, 64, None, P, backward=True)
+    y2 = torch.randn(2 * 1025, D, device="cuda").to(torch.bfloat16)   # 512 px: 1025 image tokens (configs[4])
     x2 = torch.randn(2 * 32, D, device="cuda").to(torch.bfloat16)
     assert not ops.xattn_supported(x2, 32, y2, 1025, None, P)
-    out = run(att, x.view(2, 64, D), y.view(2, 577, D), None, True)  # "auto" takes the composition
+    assert ops.xattn_supported(y2, 1025, x2, 32, None, P, backward=True)
+    out = run(att, x.view(2, 64, D), y.view(2, 577, D), None, True)   # "auto" takes the composition
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("B,T,I", [(2, 64, 577), (3, 32, 1025), (2, 64, 1025), (1, 64, 65)])
+def test_image_queries_at_pretraining_and_512px_shapes(B, T, I):
+    """m3ae_xattn_supported widened (round 3): 64 text keys (pre-training) and 1025 image tokens (configs[4]) through the
+    one-launch image-query kernel, against the fp32 reference of the reference's formulation."""
+    att, _ = make(seed=B + T + I)
+    xt = torch.randn(B, T, D, device="cuda").to(torch.bfloat16)
+    xi = torch.randn(B, I, D, device="cuda").to(torch.bfloat16)
+    mt = torch.zeros(B, T, device="cuda")
+    mt[:, T - 11:] = -10000.0
+    mt[0, 3:] = -10000.0
+    for mask in (mt, None):
+        assert ops.xattn_supported(xi.view(-1, D), I, xt.view(-1, D), T, mask, att.block_params())
+        ref = reference(att, xi, xt, mask)
+        u, f = run(att, xi, xt, mask, False), run(att, xi, xt, mask, True)
+        eu, ef = rms(u - ref), rms(f - ref)
+        assert torch.isfinite(f).all()
+        assert ef < max(1.5 * eu, 8e-3), f"rms error fused {ef:.5f} vs unfused {eu:.5f}"
+        assert (f - ref).abs().max().item() < 0.08
+        if mask is not None:
+            y2 = xt.clone()
+            y2[mask < 0] = 7.0
+            assert torch.equal(run(att, xi, y2, mask, True), f)
+
+
+@pytest.mark.parametrize("pdrop", [0.0, 0.1])
+@pytest.mark.parametrize("B,I", [(3, 577), (2, 130), (37, 33)])
+def test_one_launch_image_query_kernel_is_bit_identical_to_the_round2_chain(B, I, pdrop):
+    """csrc/xflash.hip keeps the scores and probabilities on chip; the round-2 chain (score GEMM + softmax epilogue, P through
+    HBM, P V' GEMM) rounds the same values to bf16 at the same places and reduces in the same order -- so the pre-LayerNorm sum,
+    the output and the saved probabilities are bit for bit the same, with and without dropout."""
+    att, _ = make(seed=B * 7 + I)
+    P = att.block_params()
+    T = 32
+    xt = torch.randn(B * T, D, device="cuda").to(torch.bfloat16)
+    xi = torch.randn(B * I, D, device="cuda").to(torch.bfloat16)
+    mt = torch.zeros(B, T, device="cuda")
+    mt[:, T - 9:] = -10000.0
+    res = []
+    try:
+        for legacy in (False, True):
+            ops.XATTN_LEGACY_CHAIN = legacy
+            ops.set_dropout_seed(1234)
+            out, saved = ops.xattn_fwd(xi, B, I, xt, T, mt, P, pdrop, need_bwd=True)
+            t = saved[4]
+            res.append((out.clone(), t["s"].clone(), t["probs"].clone(), t["probs_drop"].clone() if pdrop > 0 else None))
+    finally:
+        ops.XATTN_LEGACY_CHAIN = False
+    (o1, s1, p1, d1), (o2, s2, p2, d2) = res
+    assert torch.equal(p1, p2)
+    if pdrop > 0:
+        assert torch.equal(d1, d2)
+    assert torch.equal(s1, s2) and torch.equal(o1, o2)
+    # a forward-only call (no saves) computes the same output
+    ops.set_dropout_seed(1234)
+    o3, _ = ops.xattn_fwd(xi, B, I, xt, T, mt, P, pdrop, need_bwd=False)
+    assert torch.equal(o3, o1)
 
 
 @pytest.mark.parametrize("stream,I", [("text", 577), ("image", 577), ("image", 145), ("text", 33)])
@@ -210,3 +273,90 @@ def test_fused_training_path_batch_rule():
             assert layer._bp.fused_cross is True
     finally:
         ops.XATTN_TRAIN_MIN_BATCH = old
+
+
+def _fp32_reference_with_gradients(att, x, y, mask, dy, pdrop, seeds):
+    """The reference's formulation (bert_model.py:253-350 cross branch, :353-364) in fp32 torch autograd on the bf16-rounded
+    inputs and weights, with the library's exported dropout masks (attention probabilities: rows (b H + h) Lq + q, columns Lk;
+    hidden: rows B Lq, columns D).  Returns (out, dx, dy_other, {parameter name: gradient})."""
+    sa, so = att.self, att.output
+    leaf = {}
+    for n, p_ in att.named_parameters():
+        leaf[n] = (p_.m3ae_c.float() if p_.dim() == 2 else p_.data.float()).clone().requires_grad_(True)
+    xf, yf = x.float().clone().requires_grad_(True), y.float().clone().requires_grad_(True)
+    B, Lq, Lk = x.shape[0], x.shape[1], y.shape[1]
+    q = xf @ leaf["self.query.weight"].t() + leaf["self.query.bias"]
+    k = yf @ leaf["self.key.weight"].t() + leaf["self.key.bias"]
+    v = yf @ leaf["self.value.weight"].t() + leaf["self.value.bias"]
+    sp = lambda t, L: t.view(B, L, H, D // H).permute(0, 2, 1, 3)
+    sc = sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) / math.sqrt(D // H)
+    if mask is not None:
+        sc = sc + mask[:, None, None, :]
+    pr = torch.softmax(sc, -1)
+    if pdrop > 0:
+        keep = ops.dropout_keep_mask(B * H * Lq, Lk, pdrop, seeds[0]).float().view(B, H, Lq, Lk)
+        pr = pr * keep / (1.0 - pdrop)
+    ctx = (pr @ sp(v, Lk)).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    dense = ctx @ leaf["output.dense.weight"].t() + leaf["output.dense.bias"]
+    if pdrop > 0:
+        keep_h = ops.dropout_keep_mask(B * Lq, D, pdrop, seeds[1]).float().view(B, Lq, D)
+        dense = dense * keep_h / (1.0 - pdrop)
+    out = torch.nn.functional.layer_norm(dense + xf, (D,), leaf["output.LayerNorm.weight"], leaf["output.LayerNorm.bias"],
+                                         so.LayerNorm.eps)
+    out.backward(dy.float())
+    return out.detach(), xf.grad, yf.grad, {n: t.grad for n, t in leaf.items()}
+
+
+@pytest.mark.parametrize("pdrop", [0.0, 0.1])
+@pytest.mark.parametrize("B,I", [(3, 577), (128, 577), (32, 145)])
+@pytest.mark.parametrize("direction", ["txt<-img", "img<-txt"])
+def test_fused_cross_attention_backward_against_fp32_autograd(direction, B, I, pdrop):
+    """m3ae_xattn_fwd + m3ae_xattn_bwd against fp32 torch autograd of the reference's formulation -- at B = 3 (one reduction
+    split), B = 32 (ksplit 4) and at B = 128, a batch the product takes this path at (ops.XATTN_TRAIN_MIN_BATCH = 96: the
+    split-K fp32-atomic weight gradients run with ksplit >= 10 there), with the -10000 key mask, with dropout through the exported
+    masks.  The composition (GEMMs + flash attention) runs on the same seeds as a yardstick: the fused path must be within
+    1.5 x its error against the fp32 reference or 2 % relative L2 (4 % under dropout), per tensor."""
+    att, store = make(seed=B + I, wscale=1.5)
+    att.train(pdrop > 0)
+    P = att.block_params()
+    T = 32
+    xt = torch.randn(B, T, D, device="cuda").to(torch.bfloat16)
+    xi = torch.randn(B, I, D, device="cuda").to(torch.bfloat16)
+    mt = torch.zeros(B, T, device="cuda")
+    mt[:, T - 9:] = -10000.0
+    mt[0, 5:] = -10000.0
+    x, y, mask = (xt, xi, None) if direction == "txt<-img" else (xi, xt, mt)
+    L, Lo = x.shape[1], y.shape[1]
+    dy = torch.randn(B * L, D, device="cuda").to(torch.bfloat16)
+    seed = 4321
+    seeds = ((seed << 32) | 1, (seed << 32) | 2)     # ops.next_dropout_seed: attention probabilities, then hidden
+    ref = _fp32_reference_with_gradients(att, x, y, mask, dy.view(B, L, D), pdrop, seeds)
+    got = {}
+    for fused in (True, False):
+        store.zero_grad()
+        ops.set_dropout_seed(seed)
+        old = ops.XATTN
+        ops.XATTN = "auto" if fused else "off"
+        try:
+            out, saved = ops._attn_sub_fwd(x.view(B * L, D), B, L, y.view(B * Lo, D), Lo, mask, P, pdrop, fused_cross=True)
+            assert isinstance(saved[0], str) is fused
+            dx, dother = ops._attn_sub_bwd(dy, saved, B, L, Lo, P)
+        finally:
+            ops.XATTN = old
+        got[fused] = (out.float().view(B, L, D), dx.float().view(B, L, D), dother.float().view(B, Lo, D),
+                      {n: p_.grad.clone() for n, p_ in att.named_parameters()})
+    rel = lambda a, b: ((a - b).double().norm() / (b.double().norm() + 1e-30)).item()
+    tol = 0.04 if pdrop > 0 else 0.02
+    names = ["out", "dx", "dother"]
+    for idx, name in enumerate(names):
+        ef, ec = rel(got[True][idx], ref[idx]), rel(got[False][idx], ref[idx])
+        assert torch.isfinite(got[True][idx]).all()
+        assert ef < max(1.5 * ec, tol), (name, ef, ec)
+    for n, g_ref in ref[3].items():
+        gf, gc = got[True][3][n], got[False][3][n]
+        if n == "self.key.bias":     # exactly zero in exact arithmetic (b_k drops out of the softmax); the fused path never touches it
+            scale = max(ref[3]["self.value.bias"].abs().max().item(), 1e-6)
+            assert gf.abs().max().item() <= 0.05 * scale, n
+            continue
+        ef, ec = rel(gf, g_ref), rel(gc, g_ref)
+        assert ef < max(1.5 * ec, tol), (n, ef, ec)

@@ -2,6 +2,7 @@
 C-ABI library loads and exports every symbol include/m3ae_hip.h declares (no compute without a GPU), and the
 product path refuses to run on the CPU instead of silently falling back."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -57,8 +58,25 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(m3ae_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"m3ae_gemm_desc", "m3ae_attn_desc"}
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    lib = _lib.lib()  # raises if the .so is missing or a symbol is absent
-    assert lib.m3ae_abi_version() == 1
+    lib = _lib.lib()  # raises if the .so is missing or a symbol is absent; also checks ABI version and descriptor sizes
+    assert lib.m3ae_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define M3AE_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_descriptor_layouts_match_header_binding_and_integration_stub():
+    """A binding with a shorter struct than the library's is read past its end: the library reports its sizeof()s
+    (m3ae_desc_sizes), the header's field lists equal the ctypes field lists name by name, and the stub printed in
+    INTEGRATION.md is the generator's output for the binding the tests exercise."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_integration_stub as gen
+    sizes = (C.c_int64 * 3)()
+    _lib.lib().m3ae_desc_sizes(sizes)
+    assert tuple(sizes) == (C.sizeof(_lib.GemmDesc), C.sizeof(_lib.AttnDesc), C.sizeof(_lib.XattnDesc))
+    for cls, name in ((_lib.GemmDesc, "m3ae_gemm_desc"), (_lib.AttnDesc, "m3ae_attn_desc"), (_lib.XattnDesc, "m3ae_xattn_desc")):
+        assert gen.header_fields(name) == [f for f, _ in cls._fields_], name
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    committed = text[text.index(gen.BEGIN) + len(gen.BEGIN):text.index(gen.END)].strip()
+    assert committed == gen.block().strip(), "run: python tools/gen_integration_stub.py --write"
 
 
 def test_no_cpu_fallback():

@@ -39,7 +39,7 @@ def main():
         res = []
         for rnd in range(2):
             for v in VARS:
-                L.m3ae_set_tuning(0, v)
+                ops.GEMM_NT_VARIANT = v
                 ms = time_it(lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k))
                 res.append((v, ms))
         best = {v: min(ms for vv, ms in res if vv == v) for v in VARS}
@@ -47,7 +47,7 @@ def main():
     # epilogue-heavy forms on the dominant shapes
     m = M
     for vv in tuple(int(v) for v in os.environ.get('EVARS', '0,4,7').split(',')):
-      L.m3ae_set_tuning(0, vv)
+      ops.GEMM_NT_VARIANT = vv
       print("variant", vv)
       for (n, k, kind) in [(3072, 768, "gelu+preact"), (3072, 768, "dgelu"), (768, 768, "bias+res"), (768, 3072, "bias+res")]:
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
@@ -64,18 +64,18 @@ def main():
             fn = lambda: ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k, bias=b, residual=aux)
         ms = time_it(fn)
         print(f"NT {m:6d}x{n:5d}x{k:5d} {kind:12s}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
-    L.m3ae_set_tuning(0, 0)
+    ops.GEMM_NT_VARIANT = 0
     for (m, n, k) in TN_SHAPES:
         dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         g = torch.zeros(n, k, device=dev)
         out = []
         for tv in (2, 5):
-            L.m3ae_set_tuning(1, tv)
+            ops.GEMM_TN_VARIANT = tv
             ms = time_it(lambda: ops.gemm(dy, 1, n, x, k, 1, g, k, n, k, m, accumulate=True))
             out.append(f"tv{tv}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.1f} TF/s")
         print(f"TN red={m:6d} out {n:5d}x{k:5d}: " + "  ".join(out), flush=True)
-    L.m3ae_set_tuning(1, -1)
+    ops.GEMM_TN_VARIANT = -1
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
 dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
 g = torch.zeros(n, k, device=dev)
 for v in (0, 4):
-    L.m3ae_set_tuning(0, v)
+    ops.GEMM_NT_VARIANT = v
     for _ in range(3):
         ops.gemm(x, k, 1, w, 1, k, y, n, m, n, k)
 for _ in range(3):

@@ -114,8 +114,14 @@ def main():
         for name, x, y, mask in (("txt<-img", xt, xi, None), ("img<-txt", xi, xt, mt)):
             tu = 1.0 if "--fused-only" in sys.argv else timeit(lambda: run(att, x, y, mask, False, pd))
             tf = timeit(lambda: run(att, x, y, mask, True, pd), int(os.environ.get("ITERS", 10)))
+            extra = ""
+            if name == "img<-txt":      # the round-2 chain (P through HBM) for comparison
+                ops.XATTN_LEGACY_CHAIN = True
+                tl = timeit(lambda: run(att, x, y, mask, True, pd), int(os.environ.get("ITERS", 10)))
+                ops.XATTN_LEGACY_CHAIN = False
+                extra = f"  round-2 chain {tl * 1e3:7.1f} us"
             print(f"B={B} p={pd} {name}: unfused {tu * 1e3:7.1f} us ({gf / tu * 1e3:6.0f} TF/s alg)  fused {tf * 1e3:7.1f} us "
-                  f"({gf / tf * 1e3:6.0f} TF/s alg)", flush=True)
+                  f"({gf / tf * 1e3:6.0f} TF/s alg){extra}", flush=True)
     if os.environ.get("XATTN_PROFILE"):
         ops.XATTN = "auto"
         import torch.profiler as tp
