@@ -327,7 +327,8 @@ def main():
             tf = XATTN_FWD_GFLOP_PER_SAMPLE * B / 1e3
             xattn = {"batch": B, "ms": round(ms, 3), "tflop": round(tf, 3), "achieved": round(tf / (ms * 1e-3), 1),
                      "unit": "TFLOP/s", "frac": round(tf / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),
-                     "path": "m3ae_xattn_fwd (csrc/xattn.hip: long-side projection absorbed into the 32-token side)"
+                     "path": "m3ae_xattn_fwd (long-side projection absorbed into the 32-token side; image queries: ONE launch, scores "
+                             "and probabilities on chip, csrc/xflash.hip; text queries: csrc/xattn.hip)"
                              if ops.XATTN != "off" else "composition (GEMM + flash attention + GEMM + LayerNorm)",
                      "note": "6 layers x 2 directions, eval-mode forward, includes the output dense + residual + LayerNorm; "
                              "tflop = the reference formulation's 17.922 GFLOP / sample (the fused path executes ~9.9)"}
@@ -363,25 +364,32 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and args.head == "cls" and args.arch == "base" and not args.no_secondary \
             and not args.rehearse_ddp:
-        # the "+T5" half of BASELINE.json's metric, timed in the same driver run: configs[2]'s recipe on one GPU
+        # the "+T5" half of BASELINE.json's metric, timed in the same driver run (configs[2]'s recipe on one GPU), and the
+        # small-per-GPU-batch regime the reference's run scripts name (per_gpu_batchsize 32: finetune_m3ae_decoder.sh:1-2,
+        # pretrain_m3ae.sh:1-2) for configs[1] and configs[2]: child processes, a few steps each
         import subprocess
-        log("secondary line: frozen M3AE-base + t5-base head, per-GPU batch 64 (child process)")
         del loss
         torch.cuda.empty_cache()
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--head", "t5", "--t5", "t5-base", "--batch", "64",
-               "--steps", str(min(args.steps, 8)), "--warmup", str(min(args.warmup, 2)), "--no-roofline", "--no-cpu-baseline",
-               "--no-secondary"] + (["--no-dropout"] if args.no_dropout else [])
-        try:
-            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-            rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
-            if pr.returncode == 0 and rows:
-                sl = json.loads(rows[-1])
-                secondary = [{k: sl[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-                                                "step_ms", "dtype", "data", "config", "final_loss")}]
-            else:
-                secondary = [{"error": f"child rc {pr.returncode}", "stderr_tail": pr.stderr[-400:]}]
-        except Exception as e:  # noqa: BLE001
-            secondary = [{"error": repr(e)}]
+        secondary = []
+        for label, extra in (("configs[2] recipe, t5-base head, per-GPU batch 64", ["--head", "t5", "--t5", "t5-base", "--batch", "64"]),
+                             ("configs[1], per-GPU batch 32", ["--batch", "32"]),
+                             ("configs[2] recipe, t5-base head, per-GPU batch 32", ["--head", "t5", "--t5", "t5-base", "--batch", "32"])):
+            log("secondary line: " + label + " (child process)")
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", *extra,
+                   "--steps", str(min(args.steps, 8)), "--warmup", str(min(args.warmup, 2)), "--no-roofline", "--no-cpu-baseline",
+                   "--no-secondary"] + (["--no-dropout"] if args.no_dropout else [])
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                if pr.returncode == 0 and rows:
+                    sl = json.loads(rows[-1])
+                    secondary.append({"what": label, **{k: sl[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                                                          "ms_per_step", "step_ms", "dtype", "data", "config",
+                                                                          "final_loss")}})
+                else:
+                    secondary.append({"what": label, "error": f"child rc {pr.returncode}", "stderr_tail": pr.stderr[-400:]})
+            except Exception as e:  # noqa: BLE001
+                secondary.append({"what": label, "error": repr(e)})
 
     if rank == 0:
         line = {

@@ -174,7 +174,12 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
         if (a.preact && a.preact_grad) {
             float dd[8];
             act_fwd_grad_fast_n<8>(x, dd, act);
+#ifdef M3AE_EXP_NT_NOSTORE
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(dd[t]));
+#else
             Vec8<TC>::st((TC*)a.preact + off, dd);
+#endif
         } else {
             if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
             act_fwd_fast_n<8>(x, act);
@@ -209,7 +214,12 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] += y[t];
     }
+#ifdef M3AE_EXP_NT_NOSTORE
+#pragma unroll
+    for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(x[t]));
+#else
     Vec8<TC>::st((TC*)a.C + off, x);
+#endif
 }
 
 // Row-contiguous epilogue: the wave's WM x 64 fp32 accumulator tile goes through its private LDS slab (32-row passes,
@@ -523,6 +533,28 @@ static int launch_nt_t(const MfmaArgs& a, hipStream_t s) {
 //   phase 2c+1 waits (counted vmcnt: the 8 loads of chunks c+2, c+3 stay in flight) for chunk c+1 BEFORE its first
 //              barrier; chunk c+1 is first read in phase 2c+2, i.e. after a barrier every wave passed post-wait.
 // ---------------------------------------------------------------------------------------------------------
+// M3AE_EXP_NT_*: timing-only experiments on the ping-pong kernels (tools/nt_exp.sh; wrong results, never in the product build):
+// operands left unstaged / staged from contiguous 1-KiB source pieces (as if stored reduction-chunk-major) / stores dropped
+#if defined(M3AE_EXP_NT_NODMA)
+#define PP_STAGE(G, ld, r0, nr, k0, tile) do { } while (0)
+#elif defined(M3AE_EXP_NT_CONTIG)
+template <int BKT, int SEGS_PER_WAVE, int NWAVES>
+DEVINL void nt_stage_contig(const bf16_t* G, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile, int wave, int lane) {
+    constexpr int CPR = BKT / 8, RPS = 64 / CPR;
+#pragma unroll
+    for (int q = 0; q < SEGS_PER_WAVE; ++q) {
+        const int seg = q * NWAVES + wave;
+        const int row = seg * RPS + lane / CPR;
+        int64_t grow = row0 + row;
+        grow = grow < nrows ? grow : nrows - 1;
+        glds16(G + (k0 / BKT) * nrows * BKT + grow * BKT + (lane % CPR) * 8, tile + seg * 1024);
+    }
+}
+#define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage_contig<CK, 2, NW>(G, ld, r0, nr, k0, tile, wave, lane)
+#else
+#define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage<CK, 2, NW>(G, ld, r0, nr, k0, tile, wave, lane)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
@@ -548,8 +580,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (c < nc) {
-            nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, smem + c * SLOT + A_BYTES, wave, lane);
-            nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, smem + c * SLOT, wave, lane);
+            PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)c * CK, smem + c * SLOT + A_BYTES);
+            PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)c * CK, smem + c * SLOT);
         }
     }
     if (nc >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
         for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<CK>(Bt, wc * 64 + j * 16 + frow, fchunk);
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + i * 16 + frow, fchunk);
-        if (more) nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES, wave, lane);
+        if (more) PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES);
         PP_FENCE();
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
         // ---------------- phase 2c + 1: rows 64..127 (the B fragments stay in registers)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
-        if (more) nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt, wave, lane);
+        if (more) PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt);
         {
             const int rem = nc - 1 - c;  // chunks after this one; chunk c + 1 must have landed before the next phase
             if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -683,8 +715,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         char* sl = smem + ((c + 2) & 3) * SLOT;
-        nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wave, lane);
-        nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wave, lane);
+        PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES);
+        PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl);
     }
     int top_wait = 0;
     // stores per wave of an interior tile's epilogue: 16 row groups x (C [+ pre-activation / derivative]); bf16 only
@@ -716,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
             for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<CK>(Bt, wc * 64 + j * 16 + frow, fchunk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + i * 16 + frow, fchunk);
-            if (more) nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES, wave, lane);
+            if (more) PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES);
             PP_FENCE();
             __builtin_amdgcn_s_barrier();
             PP_FENCE();
@@ -735,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
             PP_FENCE();
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
-            if (more) nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt, wave, lane);
+            if (more) PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt);
             {
                 const int rem = nc - 1 - c;
                 if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -770,8 +802,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 char* sl = smem + ((c + 2) & 3) * SLOT;
-                nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES, wave, lane);
-                nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl, wave, lane);
+                PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)c * CK, sl + A_BYTES);
+                PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl);
             }
         }
         if (a.c_f32) epilogue_rows<float, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
@@ -783,8 +815,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         PP_FENCE();
         {
             char* sl = smem + ((2 + 2) & 3) * SLOT;
-            nt_stage<CK, 2, NW>(a.B, a.ldb, n0, a.N, (int64_t)2 * CK, sl + A_BYTES, wave, lane);
-            nt_stage<CK, 2, NW>(a.A, a.lda, m0, a.M, (int64_t)2 * CK, sl, wave, lane);
+            PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)2 * CK, sl + A_BYTES);
+            PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)2 * CK, sl);
         }
         v = vn;
     }

@@ -15,6 +15,19 @@ when every parameter in it has reported that many times; a report that arrives a
 error (`relearn()`), never a silently half-reduced gradient.  Averaging (1 / world_size) is folded into the fused AdamW kernel's
 `grad_scale`, not applied to the buffer.  The 6 tensors that never receive a gradient are not in the
 buffer at all -- no `find_unused_parameters` pass.
+
+Bucket order (round 3).  The flat buffer is laid out optimizer group by optimizer group, and inside a group in module
+(= forward execution) order, so backward completes a group's parameters from its END towards its start.  Buckets are
+therefore cut walking every group BACKWARDS from its last parameter, a full bucket every `bucket_bytes`, except that the
+group's first ~`tail_bytes` -- the parameters whose gradients arrive last (patch embedding, first encoder blocks) -- are a
+bucket of their own: the all-reduce that starts after the last backward kernel, the only one nothing overlaps, moves
+~`tail_bytes` instead of up to `bucket_bytes`.  `finish_order` records the order in which buckets completed on the
+last step (tests; DESIGN.md 7 states the exposed-communication prediction this is meant to falsify).
+
+`grad_dtype="bf16"`: a bucket is rounded to bf16 into a staging buffer, all-reduced at half the bytes (0.64 GB instead of
+1.29 GB per step at M3AE-base) and written back as fp32 before the optimizer step.  Every rank's addend is rounded once
+(relative 2^-9) and the sum is accumulated in bf16 by the collective: the reduced gradient differs from the fp32 all-reduce
+by <= ~1e-2 relative per element at world size 8 (stated tolerance; the AdamW update is a ratio m / sqrt(v) and moves less).
 """
 import torch
 import torch.distributed as dist
@@ -23,25 +36,47 @@ from . import ops
 
 
 class FlatGradReducer:
-    def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True, collective=None, world=None):
+    def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True, collective=None, world=None,
+                 tail_bytes=8 << 20, grad_dtype="fp32"):
         """`collective(tensor) -> handle with .wait()` replaces `dist.all_reduce(SUM, async)` (tests: a summing stand-in
         that plays the other ranks); `world` then names the emulated world size."""
         self.store, self.group, self.overlap = store, group, overlap
         self.collective = collective
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        assert grad_dtype in ("fp32", "bf16")
+        self.grad_dtype = grad_dtype
+        self._stage = None     # bf16 staging buffer (grad_dtype == "bf16"), allocated on first use
         n = store.trainable_end
-        per = max(1, bucket_bytes // 4)
-        # bucket boundaries on parameter boundaries
-        bounds, cur = [0], 0
+        per, tail = max(1, bucket_bytes // 4), max(1, min(tail_bytes, bucket_bytes) // 4)
         params = []
         for gi in range(6):
             for name, p in store.groups[gi]:
-                params.append((store.offset[id(p)], p))
+                if store.offset[id(p)] < n:
+                    params.append((store.offset[id(p)], gi, p))
         params.sort(key=lambda t: t[0])
-        for off, p in params:
-            if off - bounds[-1] >= per:
-                bounds.append(off)
-        bounds.append(n)
+        cuts = {0, n}
+        i = 0
+        while i < len(params):
+            j = i
+            while j < len(params) and params[j][1] == params[i][1]:
+                j += 1
+            offs = [t[0] for t in params[i:j]]                   # one optimizer group: [g0, g1) of the flat buffer
+            g0, g1 = offs[0], (params[j][0] if j < len(params) else n)
+            cuts.update((g0, g1))
+            # the group's first parameters (>= `tail` elements of them) are the gradients that arrive last: their own bucket
+            t_cut = next((off for off in offs if off - g0 >= tail), g1)
+            cuts.add(t_cut)
+            hi = g1                                              # the rest: walk the group backwards (= backward execution
+            for off in reversed(offs):                           # order), a full bucket every `per` elements
+                if off <= t_cut:
+                    break
+                if hi - off >= per:
+                    cuts.add(off)
+                    hi = off
+            i = j
+        params = [(off, p) for off, _, p in params]
+        params.sort(key=lambda t: t[0])
+        bounds = sorted(cuts)
         self.bounds = bounds
         self.nb = len(bounds) - 1
         self.bucket_of, self.pending0 = {}, [0] * self.nb
@@ -76,6 +111,7 @@ class FlatGradReducer:
                 self.pending[bi] = -1 if (n == 0 or self.pending[bi] < 0) else self.pending[bi] + n
         self.launched = [False] * self.nb
         self.handles = []
+        self._order = []
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
@@ -116,12 +152,19 @@ class FlatGradReducer:
         if self.launched[bi]:
             return
         self.launched[bi] = True
+        self._order.append(bi)
         a, b = self.bounds[bi], self.bounds[bi + 1]
         if b > a:
+            buf = self.store.grad[a:b]
+            if self.grad_dtype == "bf16":
+                if self._stage is None:
+                    self._stage = torch.empty(self.store.trainable_end, dtype=torch.bfloat16, device=self.store.grad.device)
+                buf = self._stage[a:b]
+                buf.copy_(self.store.grad[a:b])      # one rounding per addend; stream-ordered before the collective
             if self.collective is not None:
-                h = self.collective(self.store.grad[a:b])
+                h = self.collective(buf)
             else:
-                h = dist.all_reduce(self.store.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append(h)
 
     def on_grad_ready(self, p):
@@ -155,6 +198,11 @@ class FlatGradReducer:
             for h in self.handles:
                 if h is not None:
                     h.wait()
+            if self.grad_dtype == "bf16" and self._stage is not None:
+                for bi in self._order:                # reduced bf16 -> the fp32 buffer the optimizer reads
+                    a, b = self.bounds[bi], self.bounds[bi + 1]
+                    if b > a:
+                        self.store.grad[a:b].copy_(self._stage[a:b])
             if self.collective is None:
                 late_any = flag.item() > 0
         if late_any:
@@ -165,7 +213,11 @@ class FlatGradReducer:
                                "objectives changes")
         if self.expected is None:
             self.expected = dict(self.count)
+        self.finish_order = list(self._order)      # buckets in the order their all-reduce was issued on this step
         self.reset()
+
+    def bucket_bytes_list(self):
+        return [(self.bounds[i + 1] - self.bounds[i]) * 4 for i in range(self.nb)]
 
     @property
     def grad_scale(self):

@@ -227,7 +227,9 @@ class M3AETransformerSS(_Base):
         h = ops.linear(cls, self.vqa_head[0].weight, self.vqa_head[0].bias)
         ln = self.vqa_head[1]
         h = ops.layer_norm(h, ln.weight, ln.bias, ln.eps, act=ops.ACT_GELU)
-        return ops.linear(h, self.vqa_head[3].weight, self.vqa_head[3].bias)
+        # 498 answers: N % 4 != 0 / K % 64 != 0 would send forward, dgrad and wgrad to the fp32-FMA generic kernel in perf mode
+        # (6 launches per step at 3 TFLOP/s); the zero-padded operand copies of ops.vocab_linear keep them on the MFMA kernels
+        return ops.vocab_linear(h, self.vqa_head[3].weight, self.vqa_head[3].bias)
 
     def forward(self, batch, test=False):
         """m3ae_module.py:314-345."""

@@ -332,6 +332,138 @@ def run_t5(tag="tiny_t5", layers=2, VOC=1100):
     print(f"[{tag}] loss", loss.item(), "trainable", len(res["trainable_names"]), "with grad", len(names))
 
 
+def run_dataset():
+    """Input-pipeline fixture: the reference's own dataset classes -- BaseDataset (base_dataset.py:12-228) through
+    ROCODataset / MedicatDataset (`get_suite`, the seeded `false_image_0` draws on Python's `random`) and VQAVQARADDataset --
+    run on the tiny arrow tables of tests/arrow_util.py, with `keys_to_transforms` stubbed (no torchvision here; pixel
+    transforms are covered elsewhere) and the vocabulary-free HashTokenizer of the tests as `dataset.tokenizer`.  Stored: index
+    maps, texts, per-sample records, the raw indices every `get_suite` call asked images for (the sample's own, then the random
+    negative's), and BaseDataset.collate's keys / text tensors for one batch."""
+    import random
+    import tempfile
+    import types
+    rs.install()
+    tr = types.ModuleType("m3ae.transforms")
+    tr.keys_to_transforms = lambda keys, size=224: [lambda img, size=size: torch.zeros(3, size, size)]
+    sys.modules["m3ae.transforms"] = tr
+    from m3ae.datasets.pretraining_medicat_dataset import MedicatDataset
+    from m3ae.datasets.pretraining_roco_dataset import ROCODataset
+    from m3ae.datasets.vqa_vqa_rad_dataset import VQAVQARADDataset
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from arrow_util import HashTokenizer, write_caption_split, write_split
+    tmp = tempfile.mkdtemp()
+    write_caption_split(tmp, "roco", "train", 7, seed=1)
+    write_caption_split(tmp, "medicat", "train", 5, seed=100)
+    write_split(tmp, "train", 6, seed=3)
+    res = {}
+    for tag, cls in (("roco", ROCODataset), ("medicat", MedicatDataset)):
+        ds = cls(tmp, ["clip"], split="train", image_size=64, max_text_len=32, draw_false_image=1, draw_false_text=0,
+                 image_only=False)
+        ds.tokenizer = HashTokenizer()
+        asked = []
+        orig = ds.get_raw_image
+        ds.get_raw_image = lambda index, image_key="image", orig=orig: (asked.append(int(index)), orig(index, image_key=image_key))[1]
+        res[f"{tag}_len"] = np.int64(len(ds))
+        res[f"{tag}_index_mapper"] = np.array([ds.index_mapper[i] for i in range(len(ds))], dtype=np.int64)
+        res[f"{tag}_corpus"] = np.array(ds.corpus)
+        recs, ids, asked_all = [], [], []
+        for i in range(len(ds)):
+            random.seed(1000 + i)
+            del asked[:]
+            smp = ds[i]
+            assert sorted(smp) == ["cap_index", "false_image_0", "image", "img_index", "raw_index", "replica", "text"]
+            recs.append([smp["img_index"], smp["cap_index"], smp["raw_index"], int(smp["replica"])])
+            ids.append(smp["text"][1]["input_ids"])
+            asked_all.append(list(asked))
+            assert smp["text"][0] == ds.all_texts[smp["img_index"]][smp["cap_index"]]
+        res[f"{tag}_records"], res[f"{tag}_input_ids"] = np.array(recs, dtype=np.int64), np.array(ids, dtype=np.int64)
+        res[f"{tag}_asked"] = np.array(asked_all, dtype=np.int64)       # [n, 2]: own raw index, the negative's raw index
+        if tag == "roco":
+            random.seed(77)
+            batch = [ds[i] for i in (0, 3, 4, 9)]
+            stub_mlm = lambda encs: {"input_ids": torch.tensor([e["input_ids"] for e in encs]),
+                                     "labels": torch.full((len(encs), 32), -100)}
+            out = ds.collate(batch, stub_mlm)
+            res["roco_collate_keys"] = np.array(sorted(out))
+            for k in ("text_ids", "text_masks", "text_labels", "text_ids_mlm", "text_labels_mlm"):
+                res["roco_collate_" + k] = out[k].numpy()
+            res["roco_collate_text"] = np.array(out["text"])
+            res["roco_collate_image_shape"] = np.array(out["image"][0].shape)
+            res["roco_collate_false_image_shape"] = np.array(out["false_image_0"][0].shape)
+            res["roco_collate_replica"] = np.array(out["replica"])
+    vq = VQAVQARADDataset(tmp, ["clip"], split="train", image_size=64, max_text_len=32)
+    vq.tokenizer = HashTokenizer()
+    res["vqa_len"] = np.int64(len(vq))
+    res["vqa_index_mapper"] = np.array([vq.index_mapper[i] for i in range(len(vq))], dtype=np.int64)
+    rows = [vq[i] for i in range(len(vq))]
+    assert sorted(rows[0]) == ["answer_types", "image", "qid", "text", "vqa_answer", "vqa_labels", "vqa_scores"]
+    res["vqa_text"] = np.array([r["text"][0] for r in rows])
+    res["vqa_input_ids"] = np.array([r["text"][1]["input_ids"] for r in rows], dtype=np.int64)
+    res["vqa_attention_mask"] = np.array([r["text"][1]["attention_mask"] for r in rows], dtype=np.int64)
+    res["vqa_answer"] = np.array([r["vqa_answer"][0] for r in rows])
+    res["vqa_labels"] = np.array([r["vqa_labels"][0] for r in rows], dtype=np.int64)
+    res["vqa_scores"] = np.array([r["vqa_scores"][0] for r in rows])
+    res["vqa_answer_types"] = np.array([r["answer_types"] for r in rows], dtype=np.int64)
+    res["vqa_qid"] = np.array([r["qid"] for r in rows], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "dataset.npz"), **res)
+    print("[dataset] roco", int(res["roco_len"]), "medicat", int(res["medicat_len"]), "vqa", int(res["vqa_len"]),
+          "collate keys", res["roco_collate_keys"].tolist())
+
+
+def run_t5_base_dims():
+    """The generative head at T5-BASE dimensions (BASELINE configs[2]: d_model 768, 12 heads of 64, d_ff 3072; 2 + 2 layers are
+    enough to exercise every dimension; vocabulary 1100).  The reference's wrapper hard-wires t5-small's width (512:
+    m3ae_t5_mm_encoder_input.py:75,123-156), so this fixture comes from the class the reference instantiates -- HF
+    T5ForConditionalGeneration -- driven directly with `inputs_embeds` / `labels`, with the deterministic weights of
+    m3ae_amd/synth.py under the reference's state_dict names (`t5.*`) and the reference's unfreeze recipe (:79-96)."""
+    rs.install()
+    import torch.nn as nn
+    from transformers import T5Config, T5ForConditionalGeneration
+    VOC, L = 1100, 2
+    cfg = T5Config(vocab_size=VOC, d_model=768, d_kv=64, d_ff=3072, num_layers=L, num_decoder_layers=L, num_heads=12,
+                   dropout_rate=0.1, feed_forward_proj="relu", tie_word_embeddings=True, decoder_start_token_id=0,
+                   pad_token_id=0, eos_token_id=1)
+    cfg._attn_implementation = "eager"
+
+    class W(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.t5 = T5ForConditionalGeneration(cfg)
+
+    torch.manual_seed(0)
+    m = W()
+    for p in m.t5.parameters():
+        p.requires_grad = False
+    for blk in m.t5.encoder.block[-4:]:
+        for p in blk.parameters():
+            p.requires_grad = True
+    for blk in m.t5.decoder.block[-4:]:
+        for p in list(blk.layer[0].parameters()) + list(blk.layer[1].parameters()):
+            p.requires_grad = True
+    synth.fill_deterministic(m)
+    m.t5.shared.weight.data.copy_(synth.det_normal("t5.shared.weight", m.t5.shared.weight.shape, std=0.02))
+    m.eval()
+    x = synth.det_normal("t5base_dims.inputs_embeds", (2, 24, 768), std=0.5)
+    lab = synth.det_randint("t5base_dims.labels", 2, VOC, (2, 5), salt=9)
+    lab[0, -1] = 1
+    lab[1, 3] = 1
+    lab[1, 4] = 0          # a padded label position (ignored by the loss after the shift to -100 below)
+    labels = lab.clone()
+    labels[labels == 0] = -100
+    out = m.t5(inputs_embeds=x, attention_mask=torch.ones(2, 24, dtype=torch.long), labels=labels, return_dict=True)
+    out.loss.backward()
+    res = {"loss": np.float64(out.loss.item()), "labels": lab.numpy(), "logits": out.logits.detach().numpy(),
+           "enc_out": out.encoder_last_hidden_state.detach()[:, :6].numpy()}
+    names, gn = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    res["grad_names"], res["grad_norm"] = np.array(names), np.array(gn)
+    np.savez_compressed(os.path.join(GOLD, "t5base_dims.npz"), **res)
+    print("[t5base_dims] loss", out.loss.item(), "with grad", len(names))
+
+
 DEC_M3AE = dict(image_size=64, hidden_size=768, num_heads=12, num_top_layer=1, input_image_embed_size=128,
                 input_text_embed_size=128, vocab_size=1000)  # hidden 768: m3ae_decoder.py:311 views CLS as [B, 2, 768]
 DEC_ARCH = dict(vision_layers=2, vision_width=128, text_layers=1, text_hidden=128, text_heads=2, text_inter=512,
@@ -483,7 +615,7 @@ def run_mlm_collate():
 
 
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "t5small", "decoder", "t5gen", "mlm"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "t5small", "decoder", "t5gen", "mlm", "dataset", "t5base"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -501,6 +633,10 @@ def main():
         run_mlm_collate()
     if "full" in what:
         run_vqa("full_vqa", rs.reference_config(), {}, full_batch(), "stat")
+    if "dataset" in what:
+        run_dataset()
+    if "t5base" in what:
+        run_t5_base_dims()
     if "large1" in what:
         # configs[4]'s tower dimensions at reduced depth: ONE ViT-L/16 block (width 1024, 16 heads, 512 x 512 = 1025 image
         # tokens), ONE RoBERTa-large layer (1024 / 16 heads / 4096), ONE co-attention layer pair (768 / 12 heads)

@@ -58,14 +58,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bucket_bytes, out):
+def _worker(rank, world, port, bucket_bytes, out, grad_dtype="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         named = make_named()
         store = FakeStore(named)
-        red = FlatGradReducer(store, bucket_bytes=bucket_bytes).attach()
+        red = FlatGradReducer(store, bucket_bytes=bucket_bytes, grad_dtype=grad_dtype).attach()
         assert red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
         for step in range(3):
             store.grad.zero_()
@@ -86,6 +86,8 @@ def _worker(rank, world, port, bucket_bytes, out):
             launched_before_finish = sum(red.launched)
             if step == 0:
                 assert launched_before_finish == 0             # learning step: everything waits for finish()
+            glue = dict(named)["vqa_head.0.bias"]              # never reports: its bucket must wait for finish()
+            assert not red.launched[red.bucket_of[id(glue)]]
             red.finish()
             for i, (n, p) in enumerate(reversed(named)):
                 expect = sum(float(r + 1) * (i + 1) + step for r in range(world))
@@ -103,12 +105,15 @@ def _worker(rank, world, port, bucket_bytes, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("bucket_bytes", [1 << 30, 4096])
-def test_flat_grad_reducer_two_ranks_gloo(bucket_bytes):
+def test_flat_grad_reducer_two_ranks_gloo(bucket_bytes, grad_dtype):
+    """grad_dtype = "bf16": the buckets travel as bf16 (half the bytes); the test's gradients are small integers, exact in
+    bf16, so the reduced values are still exact."""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out, grad_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -116,11 +121,48 @@ def test_flat_grad_reducer_two_ranks_gloo(bucket_bytes):
         assert p.exitcode == 0
     res = sorted(out.get(timeout=10) for _ in range(2))
     nb = res[0][1]
+    ngroups = len({param_group_of(n) for n, _ in make_named()})
     if bucket_bytes == 4096:
-        assert nb > 2                      # several buckets on parameter boundaries
+        assert nb > ngroups                # several buckets per group, on parameter boundaries
         assert res[0][2] >= nb - 2         # most buckets were launched during "backward" (overlap), not in finish()
     else:
-        assert nb == 1 and res[0][2] == 0  # the unreported gradient keeps the single bucket for finish()
+        assert nb == ngroups               # buckets never span optimizer groups (each group is walked from its end)
+        assert res[0][2] == nb - 1         # ... and only the bucket of the unreported gradient waits for finish()
+
+
+def test_buckets_are_cut_from_the_end_of_each_group_and_the_last_to_finish_is_small():
+    """Backward completes a group's parameters from its end towards its start: full buckets are cut walking the group
+    backwards, what is left at its start (the gradients that arrive last) in pieces of at most tail_bytes -- the all-reduce
+    that nothing overlaps is the small one (ddp.py, "Bucket order")."""
+    torch.manual_seed(0)
+    named = [(f"vision_encoder.visual.transformer.resblocks.{i}.mlp.c_fc.weight", torch.nn.Parameter(torch.zeros(64, 40)))
+             for i in range(12)]
+    named += [(f"vision_encoder.visual.transformer.resblocks.{i}.mlp.c_fc.bias", torch.nn.Parameter(torch.zeros(64)))
+              for i in range(12)]
+    store = FakeStore(named)
+    per_param = 64 * 40 * 4
+    red = FlatGradReducer(store, bucket_bytes=4 * per_param, tail_bytes=per_param, world=2,
+                          collective=lambda t: None)
+    sizes = red.bucket_bytes_list()
+    g_w = param_group_of(named[0][0])
+    w_offs = sorted(store.offset[id(p)] for n, p in named if param_group_of(n) == g_w)
+    first_bucket = red.bucket_of[id(named[0][1])]            # block 0's weight: the group's start, finishes last
+    assert sizes[first_bucket] <= per_param + ALIGN * 4
+    assert max(sizes) <= 5 * per_param                       # a full bucket + at most one parameter
+    assert red.bounds[0] == 0 and red.bounds[-1] == store.trainable_end
+    red.attach()
+    try:
+        for step in range(2):
+            for n, p in reversed(named):                     # "backward": reverse module order
+                red.on_grad_ready(p)
+            red.finish()
+        # on the second step buckets were released as they completed: the weight group's buckets in descending offset order,
+        # its small first bucket last
+        order_w = [bi for bi in red.finish_order if red.bounds[bi] in w_offs or red.bounds[bi] == w_offs[0]]
+        assert order_w[-1] == first_bucket
+        assert order_w == sorted(order_w, reverse=True)
+    finally:
+        red.detach()
 
 
 def test_bucket_boundaries_are_parameter_aligned_and_cover_buffer():

@@ -139,9 +139,16 @@ def test_tiny_pretrain_objectives_fp32():
     assert abs(gn - float(g["global_grad_norm"])) < 1e-3 * float(g["global_grad_norm"])
 
 
-def test_tiny_pretrain_step_bf16_against_reference_gradients():
+@pytest.mark.parametrize("cross_rule", ["fused", "default"])
+def test_tiny_pretrain_step_bf16_against_reference_gradients(cross_rule):
     """configs[3] heads in perf mode (bf16 storage): step loss and gradient norms of the reference's fp32 run within the
-    stated bf16 bounds (loss rtol 2e-3... here 1e-2 on a 3-term loss, global gradient norm 5 %, large per-parameter norms 15 %)."""
+    stated bf16 bounds (loss rtol 2e-3... here 1e-2 on a 3-term loss, global gradient norm 5 %, large per-parameter norms 15 %).
+    cross_rule: "fused" = the cross-attention sub-blocks on the fused training path (conftest lowers the batch threshold),
+    "default" = the product's rule (ops.XATTN_TRAIN_MIN_BATCH = 96: this batch takes the composition) -- the path the
+    reference's own run scripts (per-GPU batch 8 / 32) take stays pinned to the reference fixtures."""
+    from m3ae_amd import ops
+    if cross_rule == "default":
+        ops.XATTN_TRAIN_MIN_BATCH = 96          # the autouse fixture restores it
     cfg = tiny_config(compute_dtype="bf16", loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0},
                       mim_layer=1, mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
     m = build(cfg, torch.bfloat16)
@@ -215,9 +222,14 @@ def test_large_tower_dims_reduced_depth_against_reference(mode):
         assert abs(gn - float(g["global_grad_norm"])) < 5e-2 * float(g["global_grad_norm"]), (gn, float(g["global_grad_norm"]))
 
 
-def test_full_size_bf16_step_and_optimizer():
+@pytest.mark.parametrize("cross_rule", ["fused", "default"])
+def test_full_size_bf16_step_and_optimizer(cross_rule):
     """configs[1] perf mode: one full training step (fwd + bwd + fused AdamW); loss close to the fp32 reference,
-    parameters move, shadows stay in sync."""
+    parameters move, shadows stay in sync.  cross_rule "default": the product's batch rule for the fused cross-attention
+    training path (B = 2 < 96: the composition), "fused": threshold 0 (conftest)."""
+    from m3ae_amd import ops
+    if cross_rule == "default":
+        ops.XATTN_TRAIN_MIN_BATCH = 96          # the autouse fixture restores it
     cfg = finetune_vqa_rad_config(compute_dtype="bf16")
     m = build(cfg, torch.bfloat16)
     g = load_golden("full_vqa.npz")
@@ -316,6 +328,41 @@ def test_full_t5_small_generative_head_against_reference_fixture(mode):
     # noise floor: with these weights the attention is nearly uniform and the q / k gradients are ~3e-4 of the total norm;
     # bf16 rounding of the activations alone is worth 1e-3 of it
     floor = (2e-6 if mode == "fp32" else 1e-3) * ref_total
+    for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        mine = params[n].grad.double().norm().item()
+        assert abs(mine - r) <= tol * r + floor, (n, mine, r)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_t5_base_dimensions_against_hf_fixture(mode):
+    """BASELINE configs[2] names a T5-BASE head: d_model 768, 12 heads of 64, d_ff 3072 (2 + 2 layers here, every dimension
+    exercised).  The reference's wrapper hard-wires t5-small's width, so the fixture (oracle/make_golden.py t5base) comes from
+    the class it instantiates -- HF T5ForConditionalGeneration -- with the deterministic weights under the reference's names and
+    its unfreeze recipe: encoder output, logits, loss and all 38 gradient norms, fp32 and bf16."""
+    dtype = torch.float32 if mode == "fp32" else torch.bfloat16
+    dims = dict(d_model=768, d_kv=64, d_ff=3072, num_layers=2, num_decoder_layers=2, num_heads=12)
+    m = _build_t5(mode, dtype, vocab=1100, dims=dims)
+    g = load_golden("t5base_dims.npz")
+    x = synth.det_normal("t5base_dims.inputs_embeds", (2, 24, 768), std=0.5).cuda().to(dtype)
+    labels = torch.from_numpy(g["labels"]).cuda()
+    labels = labels.masked_fill(labels == 0, -100)
+    m.store.zero_grad()
+    out = m.t5(x, labels)
+    logits = out.logits.detach().float().cpu().numpy()
+    enc = out.encoder_last_hidden_state.detach().float().cpu().numpy()[:, :6]
+    if mode == "fp32":
+        np.testing.assert_allclose(enc, g["enc_out"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(logits, g["logits"], rtol=1e-3, atol=2e-5)
+        assert abs(out.loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    else:
+        assert np.abs(logits - g["logits"]).max() < 0.05 * max(1.0, np.abs(g["logits"]).max())
+        assert abs(out.loss.item() - float(g["loss"])) < 5e-3 * float(g["loss"])
+    out.loss.backward()
+    params = dict(m.named_parameters())
+    tol = 2e-3 if mode == "fp32" else 8e-2
+    ref_total = float(np.sqrt((g["grad_norm"] ** 2).sum()))
+    floor = (2e-6 if mode == "fp32" else 1e-3) * ref_total
+    assert len(g["grad_names"]) == 38
     for n, r in zip(g["grad_names"].tolist(), g["grad_norm"]):
         mine = params[n].grad.double().norm().item()
         assert abs(mine - r) <= tol * r + floor, (n, mine, r)
@@ -846,13 +893,15 @@ def test_grad_reducer_over_rccl_single_rank_group():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode):
+@pytest.mark.parametrize("mode,buckets", [("fp32", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")])
+def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode, buckets):
     """Data-parallel semantics end to end (main.py:59-63: Lightning DDP averages the ranks' gradients): ONE batch of 4 is
     split into two "virtual ranks" of 2 that run one after the other through the reducer's real hook path -- buckets
     released from the wgrad-completion hooks, SUM collective, 1 / world in the AdamW kernel -- with a summing stand-in for
     the collective that plays the other rank; after three optimizer steps the parameters equal those of three steps on the
-    un-split batch of 4 (BCE `mean` over the batch: the mean of two half-batch means)."""
+    un-split batch of 4 (BCE `mean` over the batch: the mean of two half-batch means).
+    buckets = "bf16": the gradient buckets travel as bf16 (FlatGradReducer(grad_dtype="bf16"): every rank's addend rounded once,
+    the sum rounded once): the parameters agree within 3 % of the distance they moved (stated tolerance, ddp.py)."""
     from m3ae_amd import ops
     from m3ae_amd.ddp import FlatGradReducer
     dtype = torch.float32 if mode == "fp32" else torch.bfloat16
@@ -889,15 +938,19 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode):
             return None
 
     def collective(t):
-        off = (t.data_ptr() - m1.store.grad.data_ptr()) // 4
+        if buckets == "bf16":
+            assert t.dtype == torch.bfloat16
+            off = (t.data_ptr() - red._stage.data_ptr()) // 2
+        else:
+            off = (t.data_ptr() - m1.store.grad.data_ptr()) // 4
         released.append(off)
         if phase["record"]:
             other[off:off + t.numel()].copy_(t)     # rank 0's bucket, as released from its hooks
         else:
-            t.add_(other[off:off + t.numel()])      # rank 1: SUM over the two ranks lands in place
+            t.add_(other[off:off + t.numel()].to(t.dtype))      # rank 1: SUM over the two ranks lands in place
         return Done()
 
-    red = FlatGradReducer(m1.store, bucket_bytes=64 << 10, collective=collective, world=2)
+    red = FlatGradReducer(m1.store, bucket_bytes=64 << 10, tail_bytes=8 << 10, collective=collective, world=2, grad_dtype=buckets)
     red.attach()
     try:
         for step in range(3):
@@ -921,7 +974,12 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode):
     # fp32: same arithmetic up to the summation order of the batch reduction; bf16: per-sample activations are identical
     # (every row is reduced in the same order wherever it sits), the split changes only fp32 accumulation order
     tol = 2e-6 if mode == "fp32" else 2e-5
-    assert (a - b).abs().max().item() < tol + 1e-3 * moved, ((a - b).abs().max().item(), moved)
+    rel = 3e-2 if buckets == "bf16" else 1e-3
+    assert (a - b).abs().max().item() < tol + rel * moved, ((a - b).abs().max().item(), moved)
+    # buckets were released in descending offset order inside every optimizer group (reverse execution order), and the bucket
+    # that holds a group's first parameters is a small one
+    sizes = red.bucket_bytes_list()
+    assert min(sizes) <= (8 << 10) + 64 * 4 * 8 and max(sizes) <= (64 << 10) + max(p.numel() for p in m1.parameters()) * 4
 
 
 def test_configure_optimizers_returns_a_torch_optimizer_and_scheduler():

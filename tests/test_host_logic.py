@@ -291,3 +291,59 @@ def test_caption_datasets_and_false_image_draws(tmp_path):
     random.seed(5)
     got = bad[0]
     assert got["img_index"] != 0
+
+
+def test_input_pipeline_against_the_reference_dataset_classes(tmp_path, golden_dir):
+    """tests/golden/dataset.npz holds what the REFERENCE's BaseDataset / ROCODataset / MedicatDataset / VQAVQARADDataset
+    (base_dataset.py:12-228 and subclasses, transform stubbed, HashTokenizer as the tokenizer; oracle/make_golden.py dataset)
+    produce on the arrow tables of tests/arrow_util.py.  m3ae_amd/data.py on the same tables: index maps, texts, token ids,
+    per-sample records, the seeded `false_image_0` draws (same consumption of Python's `random`), and the collate's text side."""
+    import random
+    from arrow_util import HashTokenizer, write_caption_split, write_split
+    from m3ae_amd import data
+    g = np.load(os.path.join(golden_dir, "dataset.npz"), allow_pickle=False)
+    write_caption_split(str(tmp_path), "roco", "train", 7, seed=1)
+    write_caption_split(str(tmp_path), "medicat", "train", 5, seed=100)
+    write_split(str(tmp_path), "train", 6, seed=3)
+    tok = HashTokenizer()
+    for tag in ("roco", "medicat"):
+        ds = data.ArrowCaptionDataset(str(tmp_path), tag, "train", 64, 32, tok, draw_false_image=1)
+        assert len(ds) == int(g[f"{tag}_len"])
+        np.testing.assert_array_equal(np.array(ds.index_mapper), g[f"{tag}_index_mapper"])
+        assert [t for texts in ds.all_texts for t in texts] == g[f"{tag}_corpus"].tolist()
+        for i in range(len(ds)):
+            random.seed(1000 + i)
+            smp = ds[i]
+            assert [smp["img_index"], smp["cap_index"], smp["raw_index"], int(smp["replica"])] == g[f"{tag}_records"][i].tolist()
+            assert smp["input_ids"] == g[f"{tag}_input_ids"][i].tolist()
+            own, neg = g[f"{tag}_asked"][i].tolist()          # raw indices the reference asked images for
+            assert own == i
+            np.testing.assert_array_equal(smp["image_u8"], ds.image_u8(ds.index_mapper[own][0]))
+            np.testing.assert_array_equal(smp["false_image_u8_0"], ds.image_u8(ds.index_mapper[neg][0]))
+    ds = data.ArrowCaptionDataset(str(tmp_path), "roco", "train", 64, 32, tok, draw_false_image=1)
+    random.seed(77)
+    batch = [ds[i] for i in (0, 3, 4, 9)]
+    stub_mlm = lambda encs: {"input_ids": torch.tensor([e["input_ids"] for e in encs]), "labels": torch.full((len(encs), 32), -100)}
+    hb = data.collate_host(batch, pin=False, mlm_collator=stub_mlm)
+    for k in ("text_ids", "text_masks", "text_ids_mlm", "text_labels_mlm"):
+        np.testing.assert_array_equal(hb[k].numpy(), g["roco_collate_" + k])
+    assert hb["text"] == g["roco_collate_text"].tolist() and hb["replica"] == g["roco_collate_replica"].tolist()
+    # key correspondence: the reference's image lists travel here as uint8 NHWC arrays (normalised on the device), its
+    # all -100 `text_labels` is created on the device (data.finish_batch); everything else keeps its name
+    ref_keys = set(g["roco_collate_keys"].tolist())
+    mine = set(hb) | {"text_labels"}
+    renamed = {"image": "image_u8", "false_image_0": "false_image_u8_0"}
+    assert {renamed.get(k, k) for k in ref_keys} <= mine
+    assert (g["roco_collate_text_labels"] == -100).all()
+    assert tuple(g["roco_collate_image_shape"]) == (4, 3, 64, 64) and hb["image_u8"].shape == (4, 64, 64, 3)
+    assert tuple(g["roco_collate_false_image_shape"]) == (4, 3, 64, 64) and hb["false_image_u8_0"].shape == (4, 64, 64, 3)
+    vq = data.ArrowVQADataset(str(tmp_path), "train", 64, 32, tok)
+    assert len(vq) == int(g["vqa_len"])
+    np.testing.assert_array_equal(np.array(vq.index_mapper), g["vqa_index_mapper"])
+    for i in range(len(vq)):
+        r = vq[i]
+        assert r["text"] == g["vqa_text"][i] and r["input_ids"] == g["vqa_input_ids"][i].tolist()
+        assert r["attention_mask"] == g["vqa_attention_mask"][i].tolist()
+        assert r["vqa_answer"] == [g["vqa_answer"][i]] and r["vqa_labels"] == [int(g["vqa_labels"][i])]
+        assert r["vqa_scores"] == [float(g["vqa_scores"][i])] and r["answer_types"] == int(g["vqa_answer_types"][i])
+        assert r["qid"] == int(g["vqa_qid"][i])

@@ -1,0 +1,7 @@
+#!/bin/bash
+# timing-only experiments on the ping-pong NT GEMM: rebuild csrc/gemm_mfma.hip with each flag set and time the step's shapes
+for flags in "" "-DM3AE_EXP_NT_NODMA" "-DM3AE_EXP_NT_CONTIG" "-DM3AE_EXP_NT_NOSTORE" "-DM3AE_EXP_NT_NODMA -DM3AE_EXP_NT_NOSTORE"; do
+    touch mm-vqa-healthcare_amd/csrc/gemm_mfma.hip
+    (cd mm-vqa-healthcare_amd && M3AE_EXTRA_HIPCC_FLAGS="$flags" python -m m3ae_amd.build > /dev/null) || exit 1
+    python tools/nt_exp.py "flags: $flags" 2>&1 | grep "^\["
+done
