@@ -550,7 +550,13 @@ DEVINL void nt_stage_contig(const bf16_t* G, int64_t ld, int64_t row0, int64_t n
         glds16(G + (k0 / BKT) * nrows * BKT + grow * BKT + (lane % CPR) * 8, tile + seg * 1024);
     }
 }
+#ifdef M3AE_EXP_NT_L2HOT
+#define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage_contig<CK, 2, NW>(G, ld, 0, nr, k0, tile, wave, lane)
+#else
 #define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage_contig<CK, 2, NW>(G, ld, r0, nr, k0, tile, wave, lane)
+#endif
+#elif defined(M3AE_EXP_NT_L2HOT)   // every tile stages rows 0..255 of both operands: the sources stay L2-resident (true hits)
+#define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage<CK, 2, NW>(G, ld, 0, nr, k0, tile, wave, lane)
 #else
 #define PP_STAGE(G, ld, r0, nr, k0, tile) nt_stage<CK, 2, NW>(G, ld, r0, nr, k0, tile, wave, lane)
 #endif
@@ -1139,7 +1145,10 @@ static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
     const int64_t tiles = (d.M / BM_) * (d.N / BN_);
     const int64_t ksteps = cdiv(d.K, 64);
     const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
-    constexpr int64_t min_steps = 16;  // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us)
+    // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us).  Shorter splits on the short reductions of the text
+    // stream at small per-GPU batches (1024-4096 rows) were measured in round 3 and LOSE: 256 rows per split took 37-43 us against
+    // 24-32 us (profiles/r03_tn_small_batch.log): the extra workgroups' atomic tiles cost more than the parallelism buys
+    constexpr int64_t min_steps = 16;
     int64_t splits = target / tiles;
     if (splits > ksteps / min_steps) splits = ksteps / min_steps;
     if (splits < 1) splits = 1;
