@@ -28,6 +28,7 @@ def main():
     js = None
     if len(sys.argv) > 3 and sys.argv[3] == "--json":
         js = (sys.argv[4], int(sys.argv[5]), sys.argv[6])
+    pairs = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[3] == "--pairs" else 0
     rows = []
     for n in sorted(set(fetch) | set(write)):
         if pats and not any(p in n for p in pats):
@@ -40,6 +41,11 @@ def main():
     print(f"{'kernel':100s} {'launches':>8s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'total MB':>10s}")
     for tot, n, c, rd, wr in sorted(rows, reverse=True)[:40]:
         print(f"{n[:100]:100s} {c:8d} {rd / 1e6:15.2f} {wr / 1e6:16.2f} {tot / 1e6:10.2f}")
+    if pairs:   # tools/xattn_pair.py ran `pairs` forward layer pairs: bytes per pair over the kernels of the sub-block
+        sel = [r for r in rows if any(t in r[1] for t in ("xf1_kernel", "xg_kernel", "xattn_", "gemm_", "ln_fwd"))]
+        tot = sum((r[3] + r[4]) * r[2] for r in sel)
+        print(f"\nfused cross-attention forward, one layer pair (both directions), fabric-side bytes: {tot / pairs / 1e9:.3f} GB "
+              f"({sum(r[2] for r in sel) / pairs:.1f} launches per pair)")
     if js:
         import json
         out = {"per_gpu_batch": js[1], "head": js[2],

@@ -21,6 +21,11 @@ step stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stat
 step fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
 step write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc -o write -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
 step mfma 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -o mfma -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
+# the fused cross-attention forward alone (north_star's kernel): kernel times and fabric-side bytes per layer pair
+step xattn_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/xattn_stats -o run -- python tools/xattn_pair.py
+step xattn_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o xfetch -- python tools/xattn_pair.py
+step xattn_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc -o xwrite -- python tools/xattn_pair.py
+python tools/pmc_traffic.py $(find $out/pmc -name 'xfetch_counter_collection.csv' | head -1) $(find $out/pmc -name 'xwrite_counter_collection.csv' | head -1) --pairs 4 > $out/xattn_pmc_traffic.txt 2>&1
 # keep what is judged small: per-kernel stats, the counter tables reduced by the tools
 find $out -name '*_kernel_stats.csv' -o -name '*_domain_stats.csv' | head
 python tools/pmc_traffic.py $(find $out/pmc -name 'fetch_counter_collection.csv' | head -1) $(find $out/pmc -name 'write_counter_collection.csv' | head -1) --json $out/pmc_traffic.json 256 cls > $out/pmc_traffic.txt 2>&1
