@@ -188,7 +188,7 @@ typedef struct {
     void* ws_dproj;               /* like `proj`                     gradient of q (dir 0) / k | v (dir 1) */
     void* ws_dz;                  /* dir 0: [B, Lq*H, D]             gradient of zctx */
     void* ws_dctx;                /* dir 0: [B*Lq, D]                gradient of ctx */
-    float* ws_vec;                /* fp32 [3 * B * H * 32] */
+    float* ws_vec;                /* fp32 [3 * B * H * T], T = min(Lq, Lk) text tokens */
     float* ws_ln;                 /* fp32 [2 * m3ae_layernorm_bwd_blocks(B*Lq) * D] */
     int32_t launch_flags;         /* M3AE_XATTN_*: per-call launch policy (the library keeps no state) */
 } m3ae_xattn_desc;
@@ -197,9 +197,9 @@ enum { M3AE_XATTN_NO_PERSISTENT = 1,  /* the internal m3ae_gemm calls never take
        M3AE_XATTN_LEGACY_CHAIN = 2    /* dir 1 forward: the round-2 chain (score GEMM + softmax epilogue, P through HBM, P V'
                                        * GEMM) instead of the one-launch kernel of csrc/xflash.hip -- A/B measurements only */ };
 /* dir 1 (image queries): Lk = 32 or 64 text keys, any Lq; probs / probs_drop may be NULL in a forward-only call (the scores and
- * probabilities then never leave the chip).  dir 0 (text queries): Lq = 32, Lk <= 640. */
+ * probabilities then never leave the chip).  dir 0 (text queries): Lq = 32 or 64, Lk <= 640. */
 int m3ae_xattn_supported(const m3ae_xattn_desc* d);   /* 1 if the fused forward covers these shapes */
-int m3ae_xattn_bwd_supported(const m3ae_xattn_desc* d);   /* 1 if m3ae_xattn_bwd does too (32 text tokens) */
+int m3ae_xattn_bwd_supported(const m3ae_xattn_desc* d);   /* 1 if m3ae_xattn_bwd does too */
 int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d);
 int m3ae_xattn_fwd(const m3ae_xattn_desc* d, void* stream);
 /* Backward of m3ae_xattn_fwd in the same absorbed form: two more per-sample products per direction (the gradient of the

@@ -58,7 +58,8 @@ struct XgArgs {
     int accumulate;                        // XE_STORE: C += (bf16 read-modify-write)
     const bf16_t* P;                       // XE_DSOFT: the probabilities, laid out like C
     const float* delta; const float* radd; // XE_DSOFT: per-row [batch][M] softmax-backward term / addend to dP (nullptr: 32-column groups / 0)
-    int drop_mode;                         // XE_DSOFT dropout index: 0: row = t*H + h, key = n;  1: head = n / 32, query = m, key = n % 32
+    int drop_mode;                         // XE_DSOFT dropout index: 0: row = t*H + h, key = n;  1: head = n / tkeys, query = m, key = n % tkeys
+    int tkeys;                             // XE_DSOFT without `delta`: columns per softmax group (32 or 64 text keys; 0 = 32)
     int trace_slot;                        // diagnostic builds (M3AE_XG_TRACE) only
 };
 
@@ -497,7 +498,9 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
         // softmax backward in the row-contiguous layout: acc = dL/d(dropped probabilities); dS = P (dP - delta) with
         // dP = keep / (1 - p) (acc + radd[row]) and delta = sum_k P dP over the softmax's extent -- given per row (whole-row
         // softmax: delta = dZ . Z + radd * rowsum, the flash-attention identity, computed by xattn_rowdot_kernel) or summed
-        // here over each 32-column group (4 adjacent lanes of the row layout).  16-row fp32 slab passes.
+        // here over each group of `tkeys` columns (4 or 8 adjacent lanes of the row layout; WN is a multiple of tkeys: the caller
+        // picks the tile).  16-row fp32 slab passes.
+        const int tk = a.tkeys ? a.tkeys : 32;
         constexpr int RS = WN * 4 + 16, PR = WN / 8, PPL = 16 * PR / 64;
         static_assert((16 * PR) % 64 == 0 && 16 * RS <= SLAB_STRIDE * 2 && PR % 4 == 0, "16-row fp32 slab pass");
         char* slab16 = smem + wave * (16 * RS);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
                     uint64_t base;
                     int k0;
                     if (a.drop_mode == 0) { base = ((uint64_t)((int64_t)bi * a.H + (m % a.H)) * a.Lq + (m / a.H)) * a.drop_ld; k0 = n; }
-                    else { base = ((uint64_t)((int64_t)bi * a.H + (n >> 5)) * a.Lq + m) * a.drop_ld; k0 = n & 31; }
+                    else { base = ((uint64_t)((int64_t)bi * a.H + n / tk) * a.Lq + m) * a.drop_ld; k0 = n % tk; }
                     drop_apply4(a.drop, base + k0, dp);
                     drop_apply4(a.drop, base + k0 + 4, dp + 4);
                 }
@@ -542,7 +545,9 @@ __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(Xg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) part = fmaf(p[e], dp[e], part);
                     part += __shfl_xor(part, 1, 64);
-                    dl = part + __shfl_xor(part, 2, 64);
+                    part += __shfl_xor(part, 2, 64);
+                    if (tk == 64) part += __shfl_xor(part, 4, 64);
+                    dl = part;
                 }
                 if (ok) {
                     float ds_[8];
@@ -886,7 +891,7 @@ extern "C" int m3ae_xattn_supported(const m3ae_xattn_desc* d) {
     if (d->H <= 0 || d->D % d->H != 0) return 0;
     const int64_t dh = d->D / d->H;
     if (I < 1 || dh % 32 != 0 || d->D % 128 != 0) return 0;
-    if (d->dir == 0) return (T == 32 && I <= 640) ? 1 : 0;   // text queries: the whole-row score tile covers 640 keys
+    if (d->dir == 0) return ((T == 32 || T == 64) && I <= 640) ? 1 : 0;   // text queries: the whole-row score tile covers 640 keys
     // image queries (xflash.hip): 32 text keys (fine-tuning) or 64 (pre-training), any number of image tokens
     if (d->launch_flags & M3AE_XATTN_LEGACY_CHAIN) return (T == 32 && I <= 640) ? 1 : 0;
     return ((T == 32 || T == 64) && d->H * T == (T == 32 ? 384 : 768) && d->D % 256 == 0) ? 1 : 0;
@@ -894,8 +899,7 @@ extern "C" int m3ae_xattn_supported(const m3ae_xattn_desc* d) {
 
 extern "C" int m3ae_xattn_bwd_supported(const m3ae_xattn_desc* d) {
     if (!m3ae_xattn_supported(d)) return 0;
-    const int64_t T = d->dir == 0 ? d->Lq : d->Lk;
-    return T == 32 ? 1 : 0;   // the backward's softmax epilogues sum over 32-column groups
+    return 1;   // round 3: 32 or 64 text tokens in both directions (the softmax-backward epilogue sums 32- or 64-column groups)
 }
 
 extern "C" int64_t m3ae_xattn_probs_ld(const m3ae_xattn_desc* d) {   // row stride (elements) of `probs` / `probs_drop`
@@ -1117,8 +1121,10 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
             a.C = dS; a.ldc = R; a.c_sb = (int64_t)I * R;
             a.P = (const bf16_t*)d.probs;
             a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
-            a.drop_mode = 1; a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
+            a.drop_mode = 1; a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T); a.tkeys = T;
+            // a wave's columns must hold whole heads: 96 = 3 x 32 (384-wide tile) or 64 (256-wide tile)
+            if (T == 32) XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
+            else XCHK((launch_xg<128, 256, 2, 4, 4, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
         }
         {   // dV' = drop(P)^T dsd ; dK' = dS^T x      (reductions over the image tokens)
             XgArgs a{};

@@ -27,7 +27,8 @@ last step (tests; DESIGN.md 7 states the exposed-communication prediction this i
 `grad_dtype="bf16"`: a bucket is rounded to bf16 into a staging buffer, all-reduced at half the bytes (0.64 GB instead of
 1.29 GB per step at M3AE-base) and written back as fp32 before the optimizer step.  Every rank's addend is rounded once
 (relative 2^-9) and the sum is accumulated in bf16 by the collective: the reduced gradient differs from the fp32 all-reduce
-by <= ~1e-2 relative per element at world size 8 (stated tolerance; the AdamW update is a ratio m / sqrt(v) and moves less).
+by <= ~1e-2 in relative L2 norm (stated tolerance, held by the two-virtual-rank GPU test; single elements whose gradient is
+rounding noise can differ by their whole value, which AdamW's m / sqrt(v) turns into a full +-lr step for those elements).
 """
 import torch
 import torch.distributed as dist

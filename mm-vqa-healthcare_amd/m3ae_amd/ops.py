@@ -690,7 +690,7 @@ def xattn_bwd(dy, saved, B, L, Lo, P, need_dother=True):
     dother = e(B * Lo, D) if need_dother else None
     L_ = _lib.lib()
     w = {"ws_ds": e(B * L, D), "ws_dscores": torch.empty_like(t["probs"]), "ws_dprime": torch.empty_like(t["prime"]),
-         "ws_dproj": torch.empty_like(t["proj"]), "ws_vec": e(3 * B * H * 32, dt=torch.float32),
+         "ws_dproj": torch.empty_like(t["proj"]), "ws_vec": e(3 * B * H * min(L, Lo), dt=torch.float32),
          "ws_ln": e(2 * L_.m3ae_layernorm_bwd_blocks(B * L) * D, dt=torch.float32)}
     if pdrop > 0:
         w["ws_dsd"] = e(B * L, D)

@@ -901,7 +901,8 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode, buckets):
     the collective that plays the other rank; after three optimizer steps the parameters equal those of three steps on the
     un-split batch of 4 (BCE `mean` over the batch: the mean of two half-batch means).
     buckets = "bf16": the gradient buckets travel as bf16 (FlatGradReducer(grad_dtype="bf16"): every rank's addend rounded once,
-    the sum rounded once): the parameters agree within 3 % of the distance they moved (stated tolerance, ddp.py)."""
+    the sum rounded once): the reduced gradient within 1e-2 relative L2 of the un-split batch's (stated tolerance, ddp.py), the
+    parameter vector after three AdamW steps within 10 % of the distance it moved."""
     from m3ae_amd import ops
     from m3ae_amd.ddp import FlatGradReducer
     dtype = torch.float32 if mode == "fp32" else torch.bfloat16
@@ -923,9 +924,12 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode, buckets):
 
     # reference: the un-split global batch, no reducer
     m0 = build(cfg, dtype)
+    g0 = None
     for step in range(3):
         m0.store.zero_grad()
         m0.training_step(full).backward()
+        if step == 0:
+            g0 = m0.store.grad.clone()           # the un-split batch's gradient at the common starting point
         m0.store.adamw_step(max_steps=10, grad_scale=1.0)
     # two virtual ranks
     m1 = build(cfg, dtype)
@@ -964,6 +968,9 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode, buckets):
                 assert len(released) == red.nb
                 if step > 0:
                     assert early >= red.nb // 2, (early, red.nb)    # the hook path really released buckets during backward
+            if step == 0:   # the reduced gradient (SUM over the two ranks) x 1 / world against the un-split batch's
+                gerr = ((m1.store.grad * 0.5 - g0).double().norm() / g0.double().norm()).item()
+                assert gerr < (1e-2 if buckets == "bf16" else (1e-5 if mode == "fp32" else 2e-3)), gerr
             m1.store.adamw_step(max_steps=10, grad_scale=red.grad_scale)
     finally:
         red.detach()
@@ -974,8 +981,15 @@ def test_two_virtual_ranks_equal_the_unsplit_global_batch_step(mode, buckets):
     # fp32: same arithmetic up to the summation order of the batch reduction; bf16: per-sample activations are identical
     # (every row is reduced in the same order wherever it sits), the split changes only fp32 accumulation order
     tol = 2e-6 if mode == "fp32" else 2e-5
-    rel = 3e-2 if buckets == "bf16" else 1e-3
-    assert (a - b).abs().max().item() < tol + rel * moved, ((a - b).abs().max().item(), moved)
+    if buckets == "fp32":
+        assert (a - b).abs().max().item() < tol + 1e-3 * moved, ((a - b).abs().max().item(), moved)
+    else:
+        # bf16 buckets: AdamW's update is m / sqrt(v) -- a parameter whose gradient is rounding noise can move by lr either way,
+        # so single elements are not comparable; the parameter vector as a whole follows the fp32-bucket run (relative L2 of the
+        # difference against the distance moved), and the reduced gradient itself was held to 1e-2 above
+        a0 = build(cfg, dtype).store.flat[: m0.store.trainable_end]
+        drift = ((a - b).double().norm() / (a - a0).double().norm()).item()
+        assert drift < 0.1, drift
     # buckets were released in descending offset order inside every optimizer group (reverse execution order), and the bucket
     # that holds a group's first parameters is a small one
     sizes = red.bucket_bytes_list()

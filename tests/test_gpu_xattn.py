@@ -120,19 +120,20 @@ def test_fused_cross_attention_dropout_uses_the_same_masks_as_the_unfused_path(d
 
 def test_fused_cross_attention_coverage_and_fallback():
     """Image queries (csrc/xflash.hip) cover 32 and 64 text keys and any number of image tokens; text queries (the whole-row
-    score tile) 32 text tokens and <= 640 image tokens; everything else takes the composition."""
+    score tile) 32 or 64 text tokens and <= 640 image tokens, forward and backward; everything else takes the composition."""
     att, _ = make(seed=6)
     P = att.block_params()
     x = torch.randn(2 * 64, D, device="cuda").to(torch.bfloat16)      # 64 text tokens (pre-training, config.py:121-147)
     y = torch.randn(2 * 577, D, device="cuda").to(torch.bfloat16)
-    assert not ops.xattn_supported(x, 64, y, 577, None, P)            # text queries: not covered
-    assert ops.xattn_supported(y, 577, x, 64, None, P)                # image queries: covered (forward)
-    assert not ops.xattn_supported(y, 577, x, 64, None, P, backward=True)
+    assert ops.xattn_supported(x, 64, y, 577, None, P, backward=True)
+    assert ops.xattn_supported(y, 577, x, 64, None, P, backward=True)
     y2 = torch.randn(2 * 1025, D, device="cuda").to(torch.bfloat16)   # 512 px: 1025 image tokens (configs[4])
     x2 = torch.randn(2 * 32, D, device="cuda").to(torch.bfloat16)
-    assert not ops.xattn_supported(x2, 32, y2, 1025, None, P)
+    assert not ops.xattn_supported(x2, 32, y2, 1025, None, P)         # text queries over 1025 keys: the composition
     assert ops.xattn_supported(y2, 1025, x2, 32, None, P, backward=True)
-    out = run(att, x.view(2, 64, D), y.view(2, 577, D), None, True)   # "auto" takes the composition
+    x3 = torch.randn(2 * 48, D, device="cuda").to(torch.bfloat16)     # 48 text tokens: not covered either way
+    assert not ops.xattn_supported(x3, 48, y, 577, None, P) and not ops.xattn_supported(y, 577, x3, 48, None, P)
+    out = run(att, x2.view(2, 32, D), y2.view(2, 1025, D), None, True)   # "auto" takes the composition
     assert torch.isfinite(out).all()
 
 
@@ -146,18 +147,23 @@ def test_image_queries_at_pretraining_and_512px_shapes(B, T, I):
     mt = torch.zeros(B, T, device="cuda")
     mt[:, T - 11:] = -10000.0
     mt[0, 3:] = -10000.0
-    for mask in (mt, None):
-        assert ops.xattn_supported(xi.view(-1, D), I, xt.view(-1, D), T, mask, att.block_params())
-        ref = reference(att, xi, xt, mask)
-        u, f = run(att, xi, xt, mask, False), run(att, xi, xt, mask, True)
+    cases = [(xi, xt, mt), (xi, xt, None)]
+    if I <= 640:      # text queries (64 tokens) over the image keys: covered up to 640 keys
+        mi = torch.zeros(B, I, device="cuda")
+        mi[B - 1, I - I // 5:] = -10000.0
+        cases += [(xt, xi, None), (xt, xi, mi)]
+    for x, y, mask in cases:
+        assert ops.xattn_supported(x.view(-1, D), x.shape[1], y.view(-1, D), y.shape[1], mask, att.block_params())
+        ref = reference(att, x, y, mask)
+        u, f = run(att, x, y, mask, False), run(att, x, y, mask, True)
         eu, ef = rms(u - ref), rms(f - ref)
         assert torch.isfinite(f).all()
         assert ef < max(1.5 * eu, 8e-3), f"rms error fused {ef:.5f} vs unfused {eu:.5f}"
         assert (f - ref).abs().max().item() < 0.08
         if mask is not None:
-            y2 = xt.clone()
+            y2 = y.clone()
             y2[mask < 0] = 7.0
-            assert torch.equal(run(att, xi, y2, mask, True), f)
+            assert torch.equal(run(att, x, y2, mask, True), f)
 
 
 @pytest.mark.parametrize("pdrop", [0.0, 0.1])
@@ -308,18 +314,19 @@ def _fp32_reference_with_gradients(att, x, y, mask, dy, pdrop, seeds):
 
 
 @pytest.mark.parametrize("pdrop", [0.0, 0.1])
-@pytest.mark.parametrize("B,I", [(3, 577), (128, 577), (32, 145)])
+@pytest.mark.parametrize("B,I,T", [(3, 577, 32), (128, 577, 32), (32, 145, 32), (3, 577, 64), (2, 1025, 32)])
 @pytest.mark.parametrize("direction", ["txt<-img", "img<-txt"])
-def test_fused_cross_attention_backward_against_fp32_autograd(direction, B, I, pdrop):
+def test_fused_cross_attention_backward_against_fp32_autograd(direction, B, I, T, pdrop):
     """m3ae_xattn_fwd + m3ae_xattn_bwd against fp32 torch autograd of the reference's formulation -- at B = 3 (one reduction
     split), B = 32 (ksplit 4) and at B = 128, a batch the product takes this path at (ops.XATTN_TRAIN_MIN_BATCH = 96: the
-    split-K fp32-atomic weight gradients run with ksplit >= 10 there), with the -10000 key mask, with dropout through the exported
-    masks.  The composition (GEMMs + flash attention) runs on the same seeds as a yardstick: the fused path must be within
+    split-K fp32-atomic weight gradients run with ksplit >= 10 there), at 64 text tokens (pre-training) and at 1025 image tokens
+    (configs[4]; image queries), with the -10000 key mask, with dropout through the exported masks.  The composition (GEMMs + flash attention) runs on the same seeds as a yardstick: the fused path must be within
     1.5 x its error against the fp32 reference or 2 % relative L2 (4 % under dropout), per tensor."""
+    if direction == "txt<-img" and I > 640:
+        pytest.skip("text queries over more than 640 image keys take the composition")
     att, store = make(seed=B + I, wscale=1.5)
     att.train(pdrop > 0)
     P = att.block_params()
-    T = 32
     xt = torch.randn(B, T, D, device="cuda").to(torch.bfloat16)
     xi = torch.randn(B, I, D, device="cuda").to(torch.bfloat16)
     mt = torch.zeros(B, T, device="cuda")
