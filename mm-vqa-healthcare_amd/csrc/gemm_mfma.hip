@@ -700,6 +700,14 @@ static int launch_nt_pp(const MfmaArgs& a, hipStream_t s) {
 // 0, 1), chunk 2 right after it, so the main loop of the next tile starts on landed data.
 // Ring slot of chunk c is (c + 2) & 3; everything else is the schedule of gemm_nt_pp_kernel.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef M3AE_NT_TRACE   // diagnostic build only (tools/nt_trace.py): shader clocks per section of the main loop, summed per workgroup
+__device__ uint64_t g_nt_trace[1024 * 2 * 8];   // [block][wave row][fragment reads, DMA issue, barrier 1, lgkmcnt wait, MFMA issue, barrier 2, chunks, -]
+#define NT_CLK() ({ __builtin_amdgcn_sched_barrier(0); uint64_t t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); t_; })
+#define NT_ACC(i) do { const uint64_t n_ = NT_CLK(); nt_acc[i] += n_ - nt_t; nt_t = n_; } while (0)
+#else
+#define NT_ACC(i) do { } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs a) {
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
@@ -725,6 +733,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)c * CK, sl);
     }
     int top_wait = 0;
+#ifdef M3AE_NT_TRACE
+    uint64_t nt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nt_t = 0;
+#endif
     // stores per wave of an interior tile's epilogue: 16 row groups x (C [+ pre-activation / derivative]); bf16 only
     const int interior_wait = a.c_f32 ? 1 : (a.preact ? 3 : 2);
     for (;;) {
@@ -744,6 +755,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
         if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
+#ifdef M3AE_NT_TRACE
+        nt_t = NT_CLK();
+#endif
         for (int c = 0; c < nc; ++c) {
             const char* At = smem + ((c + 2) & 3) * SLOT;
             const char* Bt = At + A_BYTES;
@@ -754,12 +768,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
             for (int j = 0; j < 4; ++j) bfr[j] = nt_frag<CK>(Bt, wc * 64 + j * 16 + frow, fchunk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + i * 16 + frow, fchunk);
+            NT_ACC(0);
             if (more) PP_STAGE(a.B, a.ldb, n0, a.N, (int64_t)(c + 3) * CK, nxt + A_BYTES);
+            NT_ACC(1);
             PP_FENCE();
             __builtin_amdgcn_s_barrier();
             PP_FENCE();
+            NT_ACC(2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            NT_ACC(3);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -768,23 +786,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            NT_ACC(4);
             PP_FENCE();
             __builtin_amdgcn_s_barrier();
             PP_FENCE();
+            NT_ACC(5);
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
+            NT_ACC(0);
             if (more) PP_STAGE(a.A, a.lda, m0, a.M, (int64_t)(c + 3) * CK, nxt);
+            NT_ACC(1);
             {
                 const int rem = nc - 1 - c;
                 if (rem >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            NT_ACC(6);
             PP_FENCE();
             __builtin_amdgcn_s_barrier();
             PP_FENCE();
+            NT_ACC(2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            NT_ACC(3);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -793,10 +818,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 + i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            NT_ACC(4);
             PP_FENCE();
             __builtin_amdgcn_s_barrier();
             PP_FENCE();
+            NT_ACC(5);
         }
+#ifdef M3AE_NT_TRACE
+        nt_acc[7] += (uint64_t)nc;
+#endif
         if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
         // every fragment read of this tile is retired, no DMA outstanding: request the next tile's chunks 0, 1 (slots 2, 3)
         const unsigned vn = v + gridDim.x;
@@ -814,6 +844,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs 
         }
         if (a.c_f32) epilogue_rows<float, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
         else epilogue_rows<bf16_t, EPI, 8, 1>(a, smem, wave, lane, m_cur + wr * 128, n_cur + wc * 64, acc);
+#ifdef M3AE_NT_TRACE
+        if (!again && lane == 0 && (wave & 3) == 0 && blockIdx.x < 1024)
+            for (int q_ = 0; q_ < 8; ++q_) g_nt_trace[((size_t)blockIdx.x * 2 + wr) * 8 + q_] = nt_acc[q_];
+#endif
         if (!again) break;
         top_wait = (m_cur + 256 <= a.M && n_cur + 256 <= a.N) ? interior_wait : 1;
         PP_FENCE();
@@ -1188,6 +1222,12 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     if (g_tn_variant == 2) return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);  // 32 KiB LDS: 3 workgroups / CU
     return launch_tn_t<128, 128, 64, 64, 2>(a, d, s);
 }
+
+#ifdef M3AE_NT_TRACE
+extern "C" int m3ae_nt_trace_dump(uint64_t* host_out) {   // diagnostic build only
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_trace), sizeof(uint64_t) * 1024 * 2 * 8);
+}
+#endif
 
 extern "C" int m3ae_gemm(const m3ae_gemm_desc* dp, void* stream) {
     if (!dp || !dp->A || !dp->B || !dp->C) return M3AE_ERR_ARG;

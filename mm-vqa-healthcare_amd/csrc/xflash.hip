@@ -11,12 +11,15 @@
 // probabilities never touch HBM in a forward-only call; a training call copies P (and drop(P)) out of the LDS image for the
 // backward (m3ae_xattn_bwd reads them).
 //
-// LDS (160 KiB):   product 1:  ring of NSLOT1 slots x (BM + R) x 64 B         (32-deep chunks of x and K')
-//                  product 2:  [P image: BM x R x 2 B = 96 KiB][ring: 3 x 16 KiB chunks of V' (32 k-rows x 256 cols)][8 x 2 KiB slabs]
+// LDS (160 KiB):   product 1:  ring of 5 slots x (BM + R) x 64 B = 160 KiB      (32-deep chunks of x and K')
+//                  product 2:  [P image: BM x R x 2 B = 96 KiB][ring: 4 x 16 KiB chunks of V' (32 k-rows x 256 cols)]; the
+//                              epilogue's eight 2-KiB slabs live in the ring slot of a pass's last chunk
 // Waves: 8 compute waves in two barrier-staggered groups (one group's MFMA cluster covers the other's fragment reads) + 4
-// loader waves that only issue the LDS-DMA pieces -- the structure and the ring protocol of xg_kernel (xattn.hip):
+// loader waves that only issue the LDS-DMA pieces -- the structure of xg_kernel (xattn.hip):
 //   compute phase c:  [fragment reads of chunk c; lgkmcnt(0)]  barrier  [MFMAs]  barrier
-//   loader  phase c:  [request chunk c + DEPTH into the slot of chunk c - 1; counted vmcnt: chunk c + 1 landed]  barrier  barrier
+//   loader  phase c:  [part of chunk c + DEPTH into the slot of chunk c - 1]  barrier  [the rest; counted vmcnt: chunk c + 1 landed]  barrier
+// Measured (profiles/r03_xflash_*.txt): 337-363 us at B = 256 for 174 GFLOP; 256 us of it with no operand staged at
+// all (the barrier-coupled structure), a tile's 66 us = prologue 5 + product 1 24 + softmax / image 5 + product 2 24 + epilogues 6.
 #include "xattn_common.h"
 #include <type_traits>
 
