@@ -586,8 +586,11 @@ def _bdata(b):
     return None if b is None else (b.data if hasattr(b, "members") else b.detach())
 
 
-# the fused cross-attention sub-block (csrc/xattn.hip): "auto" = whenever the shapes are covered (bf16, 32 text tokens,
-# <= 640 image tokens); "off" = always the composition q / kv GEMM + flash attention + output GEMM + LayerNorm
+# the fused cross-attention sub-block (csrc/xattn.hip, csrc/xflash.hip): "auto" = whenever the shapes are covered AND absorbing
+# the long side's projection saves work (heads x text tokens < hidden width: 32 text tokens; at 64 the absorbed products are as
+# large as the projections they replace and the fused path measures SLOWER than the composition -- forward 459 vs 331 us,
+# training +25 %, profiles/r03_xattn_T64_fused_vs_composition.log); "always" = whenever covered (tests, tools); "off" = always the
+# composition q / kv GEMM + flash attention + output GEMM + LayerNorm
 XATTN = os.environ.get("M3AE_XATTN", "auto")
 # training (a backward will be asked): "auto" = fused forward + fused backward, "off" = the composition
 XATTN_TRAIN = os.environ.get("M3AE_XATTN_TRAIN", "auto")
@@ -623,6 +626,8 @@ def xattn_supported(h2, L, other2, Lo, mask, P, backward=False):
     whose input still needs a gradient takes the composition)."""
     if XATTN == "off" or h2.dtype != torch.bfloat16 or other2.shape[1] != h2.shape[1]:
         return False
+    if XATTN != "always" and P.heads * min(L, Lo) >= h2.shape[1]:
+        return False                      # covered, but not profitable (see XATTN above)
     if getattr(P.w_q, "m3ae_t", None) is None or getattr(P.w_kv, "m3ae_t", None) is None or getattr(P.w_o, "m3ae_t", None) is None:
         return False
     d = XattnDesc()

@@ -12,7 +12,7 @@ from m3ae_amd import ops, synth  # noqa: E402
 from m3ae_amd.modules.bert_model import BertAttention  # noqa: E402
 from m3ae_amd.param_store import ParamStore  # noqa: E402
 
-D, H, T, I = 768, 12, 32, int(os.environ.get("I", 577))
+D, H, T, I = 768, 12, int(os.environ.get("T", 32)), int(os.environ.get("I", 577))
 dev = "cuda"
 
 
@@ -53,7 +53,7 @@ def reference(att, x, y, mask):
 
 
 def run(att, x, y, mask, fused, pdrop=0.0):
-    ops.XATTN = "auto" if fused else "off"
+    ops.XATTN = "always" if fused else "off"
     with torch.no_grad():
         return att(x, None, y, mask, pdrop=pdrop)
 

@@ -10,6 +10,7 @@ import torch  # noqa: E402
 from m3ae_amd import ops  # noqa: E402
 import xattn_bench as xb  # noqa: E402
 
+ops.XATTN = "always"   # also where the product's auto rule prefers the composition (64 text tokens)
 att, store = xb.make(2.0)
 att.train()
 B = int(os.environ.get("B", 256))
@@ -37,4 +38,4 @@ for pd in (0.1, 0.0):
                 ts.append(1.0)
                 continue
             ts.append(xb.timeit(lambda: fb(x, y, mask, fused, pd), int(os.environ.get("ITERS", 5))))
-        print(f"B={B} p={pd} {name} fwd+bwd: composition {ts[0] * 1e3:7.1f} us  fused {ts[1] * 1e3:7.1f} us", flush=True)
+        print(f"B={B} T={xb.T} p={pd} {name} fwd+bwd: composition {ts[0] * 1e3:7.1f} us  fused {ts[1] * 1e3:7.1f} us", flush=True)
