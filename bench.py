@@ -113,6 +113,8 @@ def main():
                          "process after the main measurement; N = 1 default run only)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
+    ap.add_argument("--ddp-grad-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="gradient bucket dtype of the data-parallel all-reduce (bf16: half the bytes over xGMI, ddp.py)")
     ap.add_argument("--rehearse-ddp", action="store_true",
                     help="single GPU only: run the N > 1 code path (one-rank RCCL group, bucketed async all-reduces from the "
                          "backward hooks, one-tile-per-workgroup NT launches) -- a rehearsal of the scaling run, not a metric")
@@ -166,7 +168,7 @@ def main():
     # is part of the step in every mode
     model.train(not args.no_dropout)
     store = model.store
-    reducer = FlatGradReducer(store)
+    reducer = FlatGradReducer(store, grad_dtype=args.ddp_grad_dtype)
     if args.rehearse_ddp and world == 1:
         reducer.world = 2          # take the hook / bucket path; the sum over one rank is the identity
     reducer.attach()
@@ -412,7 +414,10 @@ def main():
                        "dropout": ("p=0.1 at every dropout site of the model (train mode, as the reference)" if model.training
                                    else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)",
                        **({"rehearsal": "N > 1 code path on one GPU (one-rank RCCL group); not the metric's configuration"}
-                          if args.rehearse_ddp else {})},
+                          if args.rehearse_ddp else {}),
+                       **({"ddp_buckets": {"count": reducer.nb, "dtype": args.ddp_grad_dtype,
+                                           "largest_MiB": round(max(reducer.bucket_bytes_list()) / 2 ** 20, 1)}}
+                          if (world > 1 or args.rehearse_ddp) else {})},
             "step_tflops_per_gpu": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3), 1) if args.head == "cls" else None,
             "mfma_frac_whole_step": round(STEP_GFLOP_PER_SAMPLE * B / 1e3 / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
             if args.head == "cls" else None,

@@ -172,15 +172,7 @@ class M3AETransformerSS(_Base):
         text_masks = batch["text_masks"]
         dt = self._dtype
         H = self.hparams.config["num_heads"]
-        # == Text Encoding (m3ae_module.py:229-236) ==
-        t = self.language_encoder.embeddings(text_ids, dt)
-        mt = self.language_encoder.get_extended_attention_mask(text_masks).contiguous()
-        for layer in self.language_encoder.encoder.layer:
-            t = layer(t, mt)
         type_emb = self.modality_type_embeddings.weight
-        # projection + modality type embedding (m3ae_module.py:235,260-263): the type row rides in the GEMM bias
-        t = ops.linear(t, self.multi_modal_language_proj.weight, self.multi_modal_language_proj.bias,
-                       extra_bias=type_emb[0])
         # == Image Encoding (m3ae_module.py:238-256) ==
         if mask_image:
             v = self.vision_encoder.forward_patch_embed(img, dt)
@@ -192,6 +184,19 @@ class M3AETransformerSS(_Base):
             v = self.vision_encoder(img, dt)
         v = ops.linear(v, self.multi_modal_vision_proj.weight, self.multi_modal_vision_proj.bias,
                        extra_bias=type_emb[image_token_type_idx])
+        # == Text Encoding (m3ae_module.py:229-236) ==
+        # The two towers are independent until the fusion layers.  The reference runs the text tower first; here it runs SECOND, so
+        # that autograd (latest-created nodes first) runs its short backward FIRST: the 154-MB word-embedding gradient is then
+        # complete ~5 % into backward and its all-reduce overlaps the image tower's backward, and the last gradients of the step
+        # are the image tower's first parameters -- the small tail bucket of ddp.FlatGradReducer.  Same values either way (only the
+        # order in which the dropout sites draw their seeds changes).
+        t = self.language_encoder.embeddings(text_ids, dt)
+        mt = self.language_encoder.get_extended_attention_mask(text_masks).contiguous()
+        for layer in self.language_encoder.encoder.layer:
+            t = layer(t, mt)
+        # projection + modality type embedding (m3ae_module.py:235,260-263): the type row rides in the GEMM bias
+        t = ops.linear(t, self.multi_modal_language_proj.weight, self.multi_modal_language_proj.bias,
+                       extra_bias=type_emb[0])
         mv = None  # all-ones image mask -> additive zeros (m3ae_module.py:253-256)
         # == Multi-Modal Fusion (m3ae_module.py:266-285): both streams read the PRE-update x, y ==
         x, y = t, v
