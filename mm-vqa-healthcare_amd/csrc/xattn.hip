@@ -764,24 +764,145 @@ int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
     return hip_launch_status();
 }
 
-// c[b][h * T + j] = scale * sum_d bq[h dh + d] * k[b T + j][h dh + d] + mask[b][j]      (dir 1: the query bias against the keys)
-__global__ __launch_bounds__(256) void xattn_colbias_kernel(const bf16_t* k, int64_t ldk, const float* bq, const float* mask,
-                                                           float* cb, int B, int T, int H, int dh, float scale) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * T * H) return;
-    const int h = idx % H, j = (idx / H) % T, b = idx / (H * T);
-    const bf16_t* kr = k + (int64_t)(b * T + j) * ldk + h * dh;
-    const float* q = bq + h * dh;
-    float s = 0.f;
-    for (int d = 0; d < dh; d += 8) {
-        const u32x4 v = *(const u32x4*)(kr + d);
+// ---- the per-head "absorbed operand" builds (K', V', Q', dZ): C[map(m)][n] = alpha * sum_{d < 64} A[m][h dh + d] B[n][h dh + d], one
+// batch item per head, M = B*T rows.  The reduction is TWO 32-deep chunks, so xg_kernel's ring never reaches steady state on
+// it: a 128 x 384 tile there is a DMA round trip, 2 MFMA clusters and 96 KiB of stores in strict sequence on a CU that holds
+// one workgroup (128 KiB ring) -- 51-54 us for 151 MB of output.  This kernel stages the whole reduction of a BM x BN tile at
+// once ((BM + BN) * 128 B of LDS), 4 waves, and is sized so that OCC workgroups share a CU: one's stores overlap the others'
+// operand round trips.  Products and their order are xg_kernel's (chunk 0 then chunk 1 into the same accumulator): bit-identical.
+template <int BM, int BN, int WAVES_M, int OCC>
+__global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
+    constexpr int GA = BM / 64, GB = BN / 64, G = GA + GB;   // 1-KiB pieces per wave and chunk
+    constexpr int A_BYTES = BM * 64, SLOT = (BM + BN) * 64;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && MI % 2 == 0 && WN % 16 == 0, "tile shape");
+    static_assert(4 * Slab<WN, 2>::BYTES <= 2 * SLOT, "slabs fit the operand tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned per_t = (unsigned)(a.tiles_m * a.tiles_n);
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);   // an XCD walks a contiguous range: a head's weight slice stays in its L2
+    const unsigned bi = wg / per_t, tt = wg - bi * per_t;
+    const int m0 = (int)(tt / a.tiles_n) * BM, n0 = (int)(tt % a.tiles_n) * BN;
+    const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
+    const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s = fmaf(__uint_as_float(v[t] << 16), q[d + 2 * t], s);
-            s = fmaf(__uint_as_float(v[t] & 0xffff0000u), q[d + 2 * t + 1], s);
-        }
+    for (int c = 0; c < 2; ++c) {
+        nt_stage_m<GB, 4>(B, a.ldb, n0, a.N, (int64_t)c * 32, smem + c * SLOT + A_BYTES, wave, lane, 0, 0);
+        nt_stage_m<GA, 4>(A, a.lda, m0, a.M, (int64_t)c * 32, smem + c * SLOT, wave, lane, 0, 0);
     }
-    cb[(int64_t)b * H * T + h * T + j] = s * scale + (mask ? mask[b * T + j] : 0.f);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    int aoff[MI], boff[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) aoff[i] = nt_frag_off<32>(wr * WM + i * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) boff[j] = A_BYTES + nt_frag_off<32>(wc * WN + j * 16 + (lane & 15), lane >> 4);
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c == 0) wait_vm<G>(); else wait_vm<0>();
+        PP_FENCE();
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of chunk c are in LDS
+        PP_FENCE();
+        const char* At = smem + c * SLOT;
+        s16x8 bfr[NJ], af[MI];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = nt_frag_at(At, boff[j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = nt_frag_at(At, aoff[i]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_FENCE();
+    __builtin_amdgcn_s_barrier();       // every fragment read is retired: the tiles become the waves' slabs
+    PP_FENCE();
+    const int mw0 = m0 + wr * WM, nw0 = n0 + wc * WN;
+    const int ncols_ok = a.N - nw0;
+    char* slab = smem + wave * Slab<WN, 2>::BYTES;
+    bf16_t* C = a.C + (int64_t)bi * a.c_sb;
+#pragma unroll
+    for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * ps + ii;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+                slab_put_bf16<WN>(slab, lane, ii, j, v);
+            }
+        }
+        slab_store_bf16<WN>(slab, lane, ncols_ok, [&](int row) -> bf16_t* {
+            const int m = mw0 + 32 * ps + row;
+            if (m >= a.M) return nullptr;
+            const int64_t crow = a.rdiv ? (int64_t)(m / a.rdiv) * a.rmul + (m % a.rdiv) : (int64_t)m;
+            return C + crow * a.ldc + nw0;
+        });
+    }
+}
+
+#ifndef M3AE_XBUILD_SHAPE
+#define M3AE_XBUILD_SHAPE 128, 192, 2, 3
+#endif
+template <int BM, int BN, int WAVES_M, int OCC>
+int launch_xbuild_t(XgArgs a, int nbatch, hipStream_t s) {
+    if (a.K != 64 || a.bias || a.rowscale || a.accumulate || a.a_div || a.b_div || a.k_switch) return M3AE_ERR_ARG;
+    constexpr int lds = 2 * (BM + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&xbuild_kernel<BM, BN, WAVES_M, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((xbuild_kernel<BM, BN, WAVES_M, OCC>), dim3((unsigned)(nbatch * a.tiles_m * a.tiles_n)), dim3(256), lds, s, a);
+    return hip_launch_status();
+}
+// K = dh = 64 is the only head size of the fused path (m3ae_xattn_supported); other head sizes keep the general template
+int launch_xbuild(const XgArgs& a, int nbatch, hipStream_t s) {
+    if (a.K == 64) return launch_xbuild_t<M3AE_XBUILD_SHAPE>(a, nbatch, s);
+    return launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, nbatch, s);
+}
+
+// c[b][h * T + j] = scale * sum_d bq[h dh + d] * k[b T + j][h dh + d] + mask[b][j]      (dir 1: the query bias against the keys)
+// One wave per text row (b, j): a lane multiplies 4 consecutive channels of each 256-channel third of the row, 64 / 4 = 16
+// adjacent lanes hold one head (dh = 64): four xor-shuffles, lane 16 g of third c writes head 4 c + g.  (Round 2 ran one THREAD
+// per (row, head) with strided 128-B reads: 10 us at B = 256; this form: the row is read once, 16 B per lane.)
+__global__ __launch_bounds__(256) void xattn_colbias_kernel(const bf16_t* k, int64_t ldk, const float* bq, const float* mask,
+                                                           float* cb, int rows, int T, int H, int dh, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / T, j = row - b * T, D = H * dh;
+    const bf16_t* kr = k + (int64_t)row * ldk;
+    const float mk = mask ? mask[row] : 0.f;
+    if (dh == 64 && D % 256 == 0) {
+        for (int c0 = 0; c0 < D; c0 += 256) {
+            const int e = c0 + 4 * lane;
+            float x[4];
+            ld_bf4(kr + e, x);
+            const f32x4 q = *(const f32x4*)(bq + e);
+            float s_ = x[0] * q[0] + x[1] * q[1] + x[2] * q[2] + x[3] * q[3];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+            if ((lane & 15) == 0) cb[(int64_t)b * H * T + (e / dh) * T + j] = s_ * scale + mk;
+        }
+        return;
+    }
+    for (int h = lane; h < H; h += 64) {   // any other head width: one lane per head
+        float s_ = 0.f;
+        for (int d = 0; d < dh; ++d) s_ = fmaf(bf2f(kr[h * dh + d]), bq[h * dh + d], s_);
+        cb[(int64_t)b * H * T + h * T + j] = s_ * scale + mk;
+    }
 }
 
 
@@ -940,7 +1061,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.M = B * T; a.N = D; a.K = dh;
             a.C = (bf16_t*)d.prime; a.ldc = (int64_t)H * D; a.c_sb = D;
             a.alpha = scale;
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK(launch_xbuild(a, H, s));
         }
         {   // P = softmax(Q' y^T + mask) per sample, whole rows per tile
             XgArgs a{};
@@ -1000,18 +1121,18 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.C = Kp; a.ldc = D; a.c_sb = (int64_t)T * D;
             a.rdiv = T; a.rmul = R;
             a.alpha = scale;
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK(launch_xbuild(a, H, s));
             // V'[b, h*T + j, :] = v_h Wo[:, h]^T
             a.A = (const bf16_t*)d.proj + D;
             a.B = (const bf16_t*)d.wo; a.ldb = D; a.b_sb = dh;               // Wo [n][h dh + d]
             a.C = Vp;
             a.alpha = 1.0f;
-            XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+            XCHK(launch_xbuild(a, H, s));
         }
         {
-            const int n = B * T * H;
-            hipLaunchKernelGGL(xattn_colbias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)d.proj,
-                               (int64_t)2 * D, d.bq, d.key_mask, d.colbias, B, T, H, dh, scale);
+            const int rows = B * T;
+            hipLaunchKernelGGL(xattn_colbias_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)d.proj,
+                               (int64_t)2 * D, d.bq, d.key_mask, d.colbias, rows, T, H, dh, scale);
             XCHK(hip_launch_status());
         }
         if (!(d.launch_flags & M3AE_XATTN_LEGACY_CHAIN)) {
@@ -1225,7 +1346,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
         a.B = (const bf16_t*)d.wkv_t + D; a.ldb = 2 * D; a.b_sb = dh;
         a.M = B * T; a.N = D; a.K = dh;
         a.C = dZ; a.ldc = (int64_t)H * D; a.c_sb = D; a.alpha = 1.0f;
-        XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, H, s)));
+        XCHK(launch_xbuild(a, H, s));
         XgArgs w{};
         w.A = dctx; w.lda = D; w.a_sb = dh;
         w.B = (const bf16_t*)d.zctx; w.ldb = (int64_t)H * D; w.b_sb = D;
