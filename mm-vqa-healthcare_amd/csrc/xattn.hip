@@ -770,8 +770,17 @@ int launch_xg(XgArgs a, int nbatch, hipStream_t s) {
 // one workgroup (128 KiB ring) -- 51-54 us for 151 MB of output.  This kernel stages the whole reduction of a BM x BN tile at
 // once ((BM + BN) * 128 B of LDS), 4 waves, and is sized so that OCC workgroups share a CU: one's stores overlap the others'
 // operand round trips.  Products and their order are xg_kernel's (chunk 0 then chunk 1 into the same accumulator): bit-identical.
-template <int BM, int BN, int WAVES_M, int OCC>
-__global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
+// PAIR: the launch builds TWO operands from two column ranges of the same projection buffer -- batch items [0, H) are the heads
+// of (A, B, C, alpha), items [H, 2H) those of (A2, B2, C2, alpha2): K' and V' of the image-query direction -- and the workgroups
+// of the first column tile of set 0 also write the query-bias vector c[b][h T + j] = scale (b_q,h . k_h[j]) + mask[b][j] from
+// the key tile they hold in LDS (the separate launch read the projection a second time for it).
+struct XbPair {
+    const bf16_t* A2; const bf16_t* B2; bf16_t* C2; float alpha2;
+    const float* bq; const float* mask; float* cb;   // cb == nullptr: no bias vector
+    int T, H; float scale;
+};
+template <int BM, int BN, int WAVES_M, int OCC, int PAIR>
+__global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a, XbPair pr) {
     constexpr int WAVES_N = 4 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
     constexpr int GA = BM / 64, GB = BN / 64, G = GA + GB;   // 1-KiB pieces per wave and chunk
     constexpr int A_BYTES = BM * 64, SLOT = (BM + BN) * 64;
@@ -785,8 +794,11 @@ __global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);   // an XCD walks a contiguous range: a head's weight slice stays in its L2
     const unsigned bi = wg / per_t, tt = wg - bi * per_t;
     const int m0 = (int)(tt / a.tiles_n) * BM, n0 = (int)(tt % a.tiles_n) * BN;
-    const bf16_t* A = a.A + (int64_t)bi * a.a_sb;
-    const bf16_t* B = a.B + (int64_t)bi * a.b_sb;
+    const bool second = PAIR && bi >= (unsigned)pr.H;
+    const unsigned head = second ? bi - (unsigned)pr.H : bi;
+    const bf16_t* A = (second ? pr.A2 : a.A) + (int64_t)head * a.a_sb;
+    const bf16_t* B = (second ? pr.B2 : a.B) + (int64_t)head * a.b_sb;
+    const float alpha = second ? pr.alpha2 : a.alpha;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         nt_stage_m<GB, 4>(B, a.ldb, n0, a.N, (int64_t)c * 32, smem + c * SLOT + A_BYTES, wave, lane, 0, 0);
@@ -822,6 +834,24 @@ __global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8_t, bfr[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
     }
+    if (PAIR && !second && n0 == 0 && pr.cb != nullptr) {
+        // both chunks of the key tile are in LDS (second barrier above): two lanes per row, 32 channels each
+        static_assert(!PAIR || BM == 128, "two lanes per tile row");
+        const int row = tid >> 1, half = tid & 1, m = m0 + row;
+        const float* bq = pr.bq + head * 64 + half * 32;
+        float s_ = 0.f;
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            const s16x8 kv = nt_frag_at(smem + half * SLOT, nt_frag_off<32>(row, g));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_ = fmaf(__uint_as_float((uint32_t)(uint16_t)kv[e] << 16), bq[g * 8 + e], s_);
+        }
+        s_ += __shfl_xor(s_, 1, 64);
+        if (half == 0 && m < a.M) {
+            const int b = m / pr.T, j = m - b * pr.T;
+            pr.cb[(int64_t)b * pr.H * pr.T + head * pr.T + j] = s_ * pr.scale + (pr.mask ? pr.mask[m] : 0.f);
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_FENCE();
     __builtin_amdgcn_s_barrier();       // every fragment read is retired: the tiles become the waves' slabs
@@ -829,7 +859,7 @@ __global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
     const int mw0 = m0 + wr * WM, nw0 = n0 + wc * WN;
     const int ncols_ok = a.N - nw0;
     char* slab = smem + wave * Slab<WN, 2>::BYTES;
-    bf16_t* C = a.C + (int64_t)bi * a.c_sb;
+    bf16_t* C = (second ? pr.C2 : a.C) + (int64_t)head * a.c_sb;
 #pragma unroll
     for (int ps = 0; ps < MI / 2; ++ps) {
 #pragma unroll
@@ -837,7 +867,7 @@ __global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
             const int i = 2 * ps + ii;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float v[4] = {acc[i][j][0] * a.alpha, acc[i][j][1] * a.alpha, acc[i][j][2] * a.alpha, acc[i][j][3] * a.alpha};
+                float v[4] = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
                 slab_put_bf16<WN>(slab, lane, ii, j, v);
             }
         }
@@ -853,24 +883,28 @@ __global__ __launch_bounds__(256, OCC) void xbuild_kernel(XgArgs a) {
 #ifndef M3AE_XBUILD_SHAPE
 #define M3AE_XBUILD_SHAPE 128, 192, 2, 3
 #endif
-template <int BM, int BN, int WAVES_M, int OCC>
-int launch_xbuild_t(XgArgs a, int nbatch, hipStream_t s) {
+template <int BM, int BN, int WAVES_M, int OCC, int PAIR>
+int launch_xbuild_t(XgArgs a, const XbPair& pr, int nbatch, hipStream_t s) {
     if (a.K != 64 || a.bias || a.rowscale || a.accumulate || a.a_div || a.b_div || a.k_switch) return M3AE_ERR_ARG;
     constexpr int lds = 2 * (BM + BN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&xbuild_kernel<BM, BN, WAVES_M, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&xbuild_kernel<BM, BN, WAVES_M, OCC, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((xbuild_kernel<BM, BN, WAVES_M, OCC>), dim3((unsigned)(nbatch * a.tiles_m * a.tiles_n)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((xbuild_kernel<BM, BN, WAVES_M, OCC, PAIR>), dim3((unsigned)(nbatch * a.tiles_m * a.tiles_n)), dim3(256), lds, s, a, pr);
     return hip_launch_status();
 }
-// K = dh = 64 is the only head size of the fused path (m3ae_xattn_supported); other head sizes keep the general template
+// K = dh = 64 is the only head size of the one-launch image-query path (m3ae_xattn_supported); other head sizes keep the general template
 int launch_xbuild(const XgArgs& a, int nbatch, hipStream_t s) {
-    if (a.K == 64) return launch_xbuild_t<M3AE_XBUILD_SHAPE>(a, nbatch, s);
+    if (a.K == 64) return launch_xbuild_t<M3AE_XBUILD_SHAPE, 0>(a, XbPair{}, nbatch, s);
     return launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_STORE>(a, nbatch, s);
+}
+// two operands of one projection buffer (+ the query-bias vector) in ONE launch; K == 64 only
+int launch_xbuild_pair(const XgArgs& a, const XbPair& pr, hipStream_t s) {
+    return launch_xbuild_t<M3AE_XBUILD_SHAPE, 1>(a, pr, 2 * pr.H, s);
 }
 
 // c[b][h * T + j] = scale * sum_d bq[h dh + d] * k[b T + j][h dh + d] + mask[b][j]      (dir 1: the query bias against the keys)
@@ -1113,6 +1147,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
         XCHK(m3ae_gemm(&g, stream));
         bf16_t* Kp = (bf16_t*)d.prime;
         bf16_t* Vp = Kp + (int64_t)B * R * D;
+        bool fused_build = false;
         {   // K'[b, h*T + j, :] = scale * k_h Wq_h
             XgArgs a{};
             a.A = (const bf16_t*)d.proj; a.lda = 2 * D; a.a_sb = dh;
@@ -1121,15 +1156,23 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.C = Kp; a.ldc = D; a.c_sb = (int64_t)T * D;
             a.rdiv = T; a.rmul = R;
             a.alpha = scale;
-            XCHK(launch_xbuild(a, H, s));
-            // V'[b, h*T + j, :] = v_h Wo[:, h]^T
-            a.A = (const bf16_t*)d.proj + D;
-            a.B = (const bf16_t*)d.wo; a.ldb = D; a.b_sb = dh;               // Wo [n][h dh + d]
-            a.C = Vp;
-            a.alpha = 1.0f;
-            XCHK(launch_xbuild(a, H, s));
+            fused_build = dh == 64;
+            if (fused_build) {   // K', V' (= v_h Wo[:, h]^T) and the query-bias vector in one launch
+                XbPair pr{};
+                pr.A2 = (const bf16_t*)d.proj + D; pr.B2 = (const bf16_t*)d.wo; pr.C2 = Vp; pr.alpha2 = 1.0f;
+                pr.bq = d.bq; pr.mask = d.key_mask; pr.cb = d.colbias; pr.T = T; pr.H = H; pr.scale = scale;
+                XCHK(launch_xbuild_pair(a, pr, s));
+            } else {
+                XCHK(launch_xbuild(a, H, s));
+                // V'[b, h*T + j, :] = v_h Wo[:, h]^T
+                a.A = (const bf16_t*)d.proj + D;
+                a.B = (const bf16_t*)d.wo; a.ldb = D; a.b_sb = dh;               // Wo [n][h dh + d]
+                a.C = Vp;
+                a.alpha = 1.0f;
+                XCHK(launch_xbuild(a, H, s));
+            }
         }
-        {
+        if (!fused_build) {
             const int rows = B * T;
             hipLaunchKernelGGL(xattn_colbias_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)d.proj,
                                (int64_t)2 * D, d.bq, d.key_mask, d.colbias, rows, T, H, dh, scale);

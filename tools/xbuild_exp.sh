@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing of the per-head operand-build kernel (csrc/xattn.hip: xbuild_kernel) at a few tile shapes: rebuild with each and time
 # both directions of the fused cross-attention forward; the LAST build is the default shape again
-for shape in "64,384,1,2" "128,256,2,2" "64,192,1,3" ""; do
+for shape in "128,256,2,2" "128,384,2,1" ""; do
     touch mm-vqa-healthcare_amd/csrc/xattn.hip
     flags=""; [ -n "$shape" ] && flags="-DM3AE_XBUILD_SHAPE=$shape"
     (cd mm-vqa-healthcare_amd && M3AE_EXTRA_HIPCC_FLAGS="$flags" python -m m3ae_amd.build > /dev/null) || exit 1
