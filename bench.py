@@ -28,6 +28,8 @@ for _p in (os.path.join(ROOT, "mm-vqa-healthcare_amd"), ROOT, os.path.join(ROOT,
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: see m3ae_amd/__init__.py (second HIP stream beside RCCL's)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -233,13 +235,30 @@ def main():
     roofline, xattn, kern_table = None, None, None
     if rank == 0 and not args.no_roofline:
         log("roofline leg")
-        ops.PROFILE = []
         reducer.detach()
-        for _ in range(2):
-            store.zero_grad()
-            train_loss().backward()
-        torch.cuda.synchronize()
-        recs, ops.PROFILE = ops.PROFILE, None
+        m3r = model.m3ae if args.head == "t5" else model
+
+        def profiled_steps():
+            ops.PROFILE = []
+            for _ in range(2):
+                store.zero_grad()
+                train_loss().backward()
+            torch.cuda.synchronize()
+            r, ops.PROFILE = ops.PROFILE, None
+            return r
+
+        recs = profiled_steps()          # as the timed region ran: the text half on its own HIP stream beside the image half
+        alone = None
+        if getattr(m3r, "two_streams", False):
+            m3r.two_streams = False      # the same launches with nothing beside them: the kernel's own rate
+            ra = [(k, d, a_, b_) for k, d, a_, b_ in profiled_steps() if k == "gemm:mfma_nt_pp"]
+            m3r.two_streams = True
+            ms_a = sum(a_.elapsed_time(b_) for _, _, a_, b_ in ra)
+            fl_a = sum(2.0 * d[0] * d[1] * d[2] * d[3] for _, d, _, _ in ra)
+            if ms_a > 0:
+                alone = {"achieved": round(fl_a / (ms_a * 1e-3) / 1e12, 1), "frac": round(fl_a / (ms_a * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                         "avg_launch_ms": round(ms_a / len(ra), 4),
+                         "how": "same launches, single-stream schedule (M3AE_TWO_STREAMS=0): no text-side kernel shares the chip"}
         agg = {}
         for kind, dims, e0, e1 in recs:
             ms = e0.elapsed_time(e1)
@@ -276,6 +295,11 @@ def main():
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": None, "launches": n // 2, "avg_launch_ms": round(ms / n, 4),
                         "flops_per_launch": fl / n}
+            if alone is not None:
+                roofline["how"] = ("HIP events on the launching stream around every launch of the kernel, in the schedule of the timed "
+                                   "region (the text half of the model runs on a second HIP stream, so some launches share the chip "
+                                   "with text-side kernels)")
+                roofline["single_stream"] = alone
             # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
             # FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read) -- only when the workload matches
             import glob
@@ -411,6 +435,7 @@ def main():
                              "trainable (main_t5_m3ae.py); the reference's extra beam-4 generate() inside every training "
                              "step (string metrics, m3ae_t5_mm_encoder_input.py:252-261) is EXCLUDED"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hip_streams": 2 if getattr(model.m3ae if args.head == "t5" else model, "two_streams", False) else 1,
                        "dropout": ("p=0.1 at every dropout site of the model (train mode, as the reference)" if model.training
                                    else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)",
                        **({"rehearsal": "N > 1 code path on one GPU (one-rank RCCL group); not the metric's configuration"}

@@ -97,6 +97,7 @@ class FlatGradReducer:
     def relearn(self):
         """Forget the learned report counts (the set of objectives / the graph changed)."""
         self.expected = None
+        self._bucket_streams = [set() for _ in range(self.nb)]
         self.reset()
 
     def reset(self):
@@ -113,6 +114,10 @@ class FlatGradReducer:
         self.launched = [False] * self.nb
         self.handles = []
         self._order = []
+        if not hasattr(self, "_bucket_streams"):
+            self._bucket_streams = [set() for _ in range(self.nb)]
+        self._bucket_events = [dict() for _ in range(self.nb)]
+        self._multi_stream = bool(getattr(self.store, "streams", None))
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
@@ -156,6 +161,19 @@ class FlatGradReducer:
         self._order.append(bi)
         a, b = self.bounds[bi], self.bounds[bi + 1]
         if b > a:
+            # the bucket's gradients may have been written from more than one stream (the module's text half runs on a side
+            # stream): the launching stream -- which the collective's own stream waits for -- first waits for the last report
+            # of this bucket on every OTHER stream (an event recorded right behind that wgrad launch: nothing later on that
+            # stream is waited for, so the two halves keep running beside each other)
+            evs = self._bucket_events[bi]
+            if evs:
+                cur = torch.cuda.current_stream()
+                for sid, (st, ev) in evs.items():
+                    if sid != cur.cuda_stream:
+                        if ev is not None:
+                            cur.wait_event(ev)
+                        else:
+                            cur.wait_stream(st)
             buf = self.store.grad[a:b]
             if self.grad_dtype == "bf16":
                 if self._stage is None:
@@ -168,6 +186,18 @@ class FlatGradReducer:
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append(h)
 
+    def _note_stream(self, bi):
+        """A report for bucket `bi` on the current stream (called right behind the wgrad launch)."""
+        cur = torch.cuda.current_stream()
+        sid = cur.cuda_stream
+        known = self._bucket_streams[bi]
+        if len(known) > 1:                       # a bucket both halves write into: remember where its last write on this stream is
+            self._bucket_events[bi][sid] = (cur, cur.record_event())
+        elif sid not in known:                   # the schedule changed after the learning step: fall back to whole-stream waits
+            known.add(sid)
+            for s2 in getattr(self.store, "streams", ()):
+                self._bucket_events[bi].setdefault(s2.cuda_stream, (s2, None))
+
     def on_grad_ready(self, p):
         pid = id(p)
         if pid not in self.bucket_of:
@@ -175,8 +205,12 @@ class FlatGradReducer:
         c = self.count.get(pid, 0) + 1
         self.count[pid] = c
         if self.expected is None:
+            if getattr(self.store, "streams", None):    # learning step: which streams write into which bucket
+                self._bucket_streams[self.bucket_of[pid]].add(torch.cuda.current_stream().cuda_stream)
             return
         bi = self.bucket_of[pid]
+        if self._multi_stream:
+            self._note_stream(bi)
         if c > self.expected.get(pid, 0):
             if self.launched[bi]:   # a contribution landed after the bucket's all-reduce was issued
                 self.late = self.store.names.get(pid, "?") if hasattr(self.store, "names") else "?"

@@ -12,6 +12,8 @@ first forward; attention probabilities are not materialised (`output_attentions`
 (`module.training`, RoBERTa p = 0.1, fusion layers p = `drop_rate`) uses the library's counter-hash masks fused into
 the kernels (seeded by `ops.set_dropout_seed`), not torch's Philox stream.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,21 @@ from ..param_store import ParamStore
 from . import objectives, prediction_heads
 from .bert_model import BertCrossLayer, RobertaModel
 from .clip_model import adapt_position_encoding, build_model
+
+class _JoinAtEndFn(torch.autograd.Function):
+    """Identity.  Its backward (among the first nodes of a backward pass) queues `main.wait_stream(side)` to run when the pass ends."""
+
+    @staticmethod
+    def forward(ctx, x, main, side):
+        ctx.streams = (main, side)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        main, side = ctx.streams
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+        return g, None, None
+
 
 try:  # drop-in for pl.Trainer when Lightning is installed on the user's side
     import pytorch_lightning as pl
@@ -137,6 +154,55 @@ class M3AETransformerSS(_Base):
         return self
 
     # ------------------------------------------------------------------------------------------------------
+    two_streams = os.environ.get("M3AE_TWO_STREAMS", "1") == "1"   # M3AE_TWO_STREAMS=0: everything on the caller's stream
+    _side_stream = None
+
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("M3AE_SIDE_PRIORITY", "0")))
+            # gradients of directly-used leaves (e.g. the modality type embeddings) arrive from nodes of either stream: intended
+            warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn_off is not None:
+                warn_off(False)
+        return self._side_stream
+
+    def _fusion_two_streams(self, text_tower, v, mt, mv, mask_image, ret, main, side, ev_inputs):
+        """The text tower and the text half of every fusion layer on a second HIP stream.  The towers are independent until the
+        fusion layers and a fusion layer's two halves read only the PREVIOUS layer's outputs, so the short text-side kernels
+        (B*32 rows: half-empty grids) fill the tail rounds of the image-side launches instead of running alone.  Events order
+        the hand-overs; `record_stream` keeps the caching allocator from recycling a tensor while the other stream still reads
+        it.  autograd runs every node's backward on the stream of its forward and inserts the same hand-overs in reverse."""
+        side.wait_event(ev_inputs)
+        mt.record_stream(side)
+        self.store.streams.update((main, side))
+        with torch.cuda.stream(side):
+            x = text_tower()
+            ev_x = side.record_event()
+        y = v
+        ev_y = main.record_event()
+        for layer_idx, (text_layer, image_layer) in enumerate(zip(self.multi_modal_language_layers,
+                                                                  self.multi_modal_vision_layers)):
+            if mask_image and self.hparams.config["mim_layer"] == layer_idx:
+                ret[f"multi_modal_text_feats_{layer_idx}"], ret[f"multi_modal_image_feats_{layer_idx}"] = x, y
+            side.wait_event(ev_y)
+            y.record_stream(side)
+            with torch.cuda.stream(side):
+                x1 = text_layer(x, y, mt, mv)
+                ev_x1 = side.record_event()
+            main.wait_event(ev_x)
+            x.record_stream(main)
+            y1 = image_layer(y, x, mv, mt)
+            ev_y = main.record_event()
+            x, y, ev_x = x1, y1, ev_x1
+        main.wait_event(ev_x)
+        x.record_stream(main)
+        if torch.is_grad_enabled():
+            # whichever of the two runs in backward queues the end-of-backward join: when loss.backward() returns, the caller's
+            # stream has waited for the side stream (the weight gradients land in the flat buffer as side effects of the nodes,
+            # not as autograd outputs, so the engine's own end-of-backward synchronisation does not cover them)
+            x, y = _JoinAtEndFn.apply(x, main, side), _JoinAtEndFn.apply(y, main, side)
+        return x, y
+
     def random_masking(self, x, mask_ratio, noise=None):
         """m3ae_module.py:153-183.  The argsort / argsort-of-argsort / gather-of-ones bookkeeping is one kernel
         (`m3ae_mask_ranks`: ranks by counting); the row gather and its gradient run in the library too."""
@@ -173,6 +239,10 @@ class M3AETransformerSS(_Base):
         dt = self._dtype
         H = self.hparams.config["num_heads"]
         type_emb = self.modality_type_embeddings.weight
+        mt = self.language_encoder.get_extended_attention_mask(text_masks).contiguous()
+        ev_inputs = None
+        if self.two_streams and img.is_cuda:   # the text tower (side stream) may start as soon as the inputs are there
+            ev_inputs = torch.cuda.current_stream().record_event()
         # == Image Encoding (m3ae_module.py:238-256) ==
         if mask_image:
             v = self.vision_encoder.forward_patch_embed(img, dt)
@@ -190,23 +260,33 @@ class M3AETransformerSS(_Base):
         # complete ~5 % into backward and its all-reduce overlaps the image tower's backward, and the last gradients of the step
         # are the image tower's first parameters -- the small tail bucket of ddp.FlatGradReducer.  Same values either way (only the
         # order in which the dropout sites draw their seeds changes).
-        t = self.language_encoder.embeddings(text_ids, dt)
-        mt = self.language_encoder.get_extended_attention_mask(text_masks).contiguous()
-        for layer in self.language_encoder.encoder.layer:
-            t = layer(t, mt)
-        # projection + modality type embedding (m3ae_module.py:235,260-263): the type row rides in the GEMM bias
-        t = ops.linear(t, self.multi_modal_language_proj.weight, self.multi_modal_language_proj.bias,
-                       extra_bias=type_emb[0])
+        side = self._side() if (self.two_streams and img.is_cuda) else None
+        main = torch.cuda.current_stream() if side is not None else None
         mv = None  # all-ones image mask -> additive zeros (m3ae_module.py:253-256)
-        # == Multi-Modal Fusion (m3ae_module.py:266-285): both streams read the PRE-update x, y ==
-        x, y = t, v
-        for layer_idx, (text_layer, image_layer) in enumerate(zip(self.multi_modal_language_layers,
-                                                                  self.multi_modal_vision_layers)):
-            if mask_image and self.hparams.config["mim_layer"] == layer_idx:
-                ret[f"multi_modal_text_feats_{layer_idx}"], ret[f"multi_modal_image_feats_{layer_idx}"] = x, y
-            x1 = text_layer(x, y, mt, mv)
-            y1 = image_layer(y, x, mv, mt)
-            x, y = x1, y1
+
+        def text_tower():
+            if side is not None:
+                text_ids.record_stream(side)
+            t = self.language_encoder.embeddings(text_ids, dt)
+            for layer in self.language_encoder.encoder.layer:
+                t = layer(t, mt)
+            # projection + modality type embedding (m3ae_module.py:235,260-263): the type row rides in the GEMM bias
+            return ops.linear(t, self.multi_modal_language_proj.weight, self.multi_modal_language_proj.bias,
+                              extra_bias=type_emb[0])
+
+        if side is None:
+            t = text_tower()
+            # == Multi-Modal Fusion (m3ae_module.py:266-285): both streams read the PRE-update x, y ==
+            x, y = t, v
+            for layer_idx, (text_layer, image_layer) in enumerate(zip(self.multi_modal_language_layers,
+                                                                      self.multi_modal_vision_layers)):
+                if mask_image and self.hparams.config["mim_layer"] == layer_idx:
+                    ret[f"multi_modal_text_feats_{layer_idx}"], ret[f"multi_modal_image_feats_{layer_idx}"] = x, y
+                x1 = text_layer(x, y, mt, mv)
+                y1 = image_layer(y, x, mv, mt)
+                x, y = x1, y1
+        else:
+            x, y = self._fusion_two_streams(text_tower, v, mt, mv, mask_image, ret, main, side, ev_inputs)
         # == Output (m3ae_module.py:287-297) ==
         cls_t = self.multi_modal_language_pooler(x)
         cls_v = self.multi_modal_vision_pooler(y)

@@ -22,7 +22,7 @@ grad_ready_hook = None  # callable(param) set by the DDP reducer
 SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
 # host-side launch policy, set by ddp.FlatGradReducer while collectives run next to backward (per-call flag in the GEMM
 # descriptor: the library itself keeps no state)
-NT_NO_PERSISTENT = False
+NT_NO_PERSISTENT = os.environ.get("M3AE_NT_NO_PERSISTENT", "0") == "1"   # (set by ddp.FlatGradReducer.attach; the env default is for A/B runs)
 # diagnostic per-call kernel selectors (m3ae_gemm_desc.launch_flags; -1 / 0 = by shape): tests compare kernel variants bit for
 # bit, tools time them; the product path never sets them
 GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = -1, -1, 0

@@ -105,6 +105,10 @@ class ParamStore:
     def __init__(self, module, cfg, device, compute_dtype=torch.bfloat16, weight_units=None, frozen=(),
                  group_fn=param_group_of, hparams_fn=group_hparams):
         self.module, self.cfg, self.device, self.compute_dtype = module, cfg, device, compute_dtype
+        # the HIP streams that carry this module's backward work when there is more than one (M3AETransformerSS runs its text
+        # half on a second stream): consumers of the flat gradient buffer that run INSIDE a backward pass (ddp.FlatGradReducer)
+        # make their own stream wait for the others
+        self.streams = set()
         self.hparams_fn = hparams_fn
         named = [(n, p) for n, p in module.named_parameters()]
         self.names = {id(p): n for n, p in named}

@@ -717,6 +717,52 @@ def test_full_size_bench_batch_properties():
     assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
 
 
+@pytest.mark.parametrize("task", ["vqa", "pretrain"])
+def test_two_stream_schedule_equals_the_single_stream_step(task):
+    """M3AETransformerSS runs its text half (RoBERTa tower + the text half of every fusion layer) on a second HIP stream
+    (modules/m3ae_module.py::_fusion_two_streams).  Same kernels, same dropout seeds, different interleaving: the forward is
+    bit-identical to the single-stream schedule and the gradients agree up to the order of the fp32 atomics -- five times in a
+    row, with the flat gradient buffer read right after backward() (the end-of-backward join is what makes that read safe)."""
+    from m3ae_amd import ops
+    if task == "vqa":
+        cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+        b = to_dev(synth.synthetic_batch(8, text_len=32, image_size=384, rank=0))
+    else:
+        cfg = tiny_config(compute_dtype="bf16", drop_rate=0.1,
+                          loss_names={"mlm": 1, "mim": 1, "itm": 1, "vqa": 0, "cls": 0, "irtr": 0},
+                          mim_layer=1, mim_decoder_hidden_size=128, mim_decoder_num_layers=2, mim_decoder_num_heads=2)
+        b = to_dev(tiny_batch(pretrain=True))
+        b["itm_labels"] = torch.tensor([1.0, 0.0])
+    m = build(cfg, torch.bfloat16)
+    m.set_task()
+
+    def step(two):
+        m.two_streams = two
+        m.train()
+        m.store.zero_grad()
+        ops.set_dropout_seed(5)
+        torch.manual_seed(3)            # the MIM masking noise of the pre-training step
+        if task == "vqa":
+            ret = m(b)
+            loss, feats = ret["vqa_loss"], ret["multi_modal_cls_feats"].float().clone()
+        else:
+            loss, feats = m.training_step(b), None
+        loss.backward()
+        return loss.item(), m.store.grad.clone(), feats
+
+    l0, g0, f0 = step(False)
+    assert len(m.store.streams) == 0
+    for _ in range(5):
+        l1, g1, f1 = step(True)
+        assert len(m.store.streams) == 2
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), (l0, l1)
+        if f0 is not None:
+            assert torch.equal(f0, f1)
+        rel = ((g1 - g0).double().norm() / g0.double().norm()).item()
+        assert rel <= 1e-5, rel
+    m.two_streams = type(m).two_streams
+
+
 def test_t5_head_training_mode_dropout_is_seeded_and_active():
     """configs[2] in train() mode: every HF-T5 dropout site (embeddings, attention weights, sub-layer outputs, inside the
     feed-forward, final norm) plus the frozen M3AE's own: reproducible from the seed, different across seeds / from eval."""
