@@ -168,8 +168,9 @@ class FlatGradReducer:
             evs = self._bucket_events[bi]
             if evs:
                 cur = torch.cuda.current_stream()
+                here = cur.cuda_stream or 0
                 for sid, (st, ev) in evs.items():
-                    if sid != cur.cuda_stream:
+                    if sid != here:
                         if ev is not None:
                             cur.wait_event(ev)
                         else:
@@ -188,15 +189,15 @@ class FlatGradReducer:
 
     def _note_stream(self, bi):
         """A report for bucket `bi` on the current stream (called right behind the wgrad launch)."""
-        cur = torch.cuda.current_stream()
-        sid = cur.cuda_stream
+        sid = ops._stream().value or 0           # raw handle: no Stream object on the common path (~700 reports per step)
         known = self._bucket_streams[bi]
         if len(known) > 1:                       # a bucket both halves write into: remember where its last write on this stream is
+            cur = torch.cuda.current_stream()
             self._bucket_events[bi][sid] = (cur, cur.record_event())
         elif sid not in known:                   # the schedule changed after the learning step: fall back to whole-stream waits
             known.add(sid)
             for s2 in getattr(self.store, "streams", ()):
-                self._bucket_events[bi].setdefault(s2.cuda_stream, (s2, None))
+                self._bucket_events[bi].setdefault(s2.cuda_stream or 0, (s2, None))
 
     def on_grad_ready(self, p):
         pid = id(p)
@@ -206,7 +207,7 @@ class FlatGradReducer:
         self.count[pid] = c
         if self.expected is None:
             if getattr(self.store, "streams", None):    # learning step: which streams write into which bucket
-                self._bucket_streams[self.bucket_of[pid]].add(torch.cuda.current_stream().cuda_stream)
+                self._bucket_streams[self.bucket_of[pid]].add(ops._stream().value or 0)
             return
         bi = self.bucket_of[pid]
         if self._multi_stream:
