@@ -117,6 +117,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise M3AEHipError(f"{LIB_PATH} is missing: build it with `python -m m3ae_amd.build` "
                                f"(or __graft_entry__.build()); this package has no CPU fallback")
+        # PyTorch-ROCm ships its own libamdhip64; a process must run on ONE HIP runtime.  Loading this library first would
+        # bring in the system runtime (DT_NEEDED) and torch would then initialise on that one: every launch of this library
+        # afterwards fails with hipErrorNoDevice (seen with __graft_entry__.build() followed by smoke() in one process).
+        # Importing torch first makes its runtime the process's runtime.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
