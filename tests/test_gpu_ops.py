@@ -34,6 +34,20 @@ def test_selftest_hardware_idioms():
     assert res[0] == 0, f"mismatches [total, mfma16, mfma32, tr_read, acc_as_operand, lds_dma] = {res}"
 
 
+def test_build_then_first_launch_in_a_fresh_process():
+    """`__graft_entry__.build()` (which loads the library) followed by the first launch in the SAME fresh process: the library must
+    not pull the system HIP runtime in before PyTorch-ROCm's own (one runtime per process; the wrong order ended in
+    hipErrorNoDevice on the first launch).  One child process, nothing else on the GPU meanwhile."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g; g.build(); from m3ae_amd import ops; r = ops.selftest(); "
+            "assert r[0] == 0, r; print('child ok')")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "child ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 136, 128), (577 * 2, 768, 768), (33, 498, 1536), (1154, 2304, 768)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nt_bias_act_residual(M, N, K, dtype):
