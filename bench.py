@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
     ap.add_argument("--ddp-grad-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="gradient bucket dtype of the data-parallel all-reduce (bf16: half the bytes over xGMI, ddp.py)")
+    ap.add_argument("--optimizer-in-backward", action="store_true",
+                    help="AdamW bucket by bucket on its own stream under backward (ddp.FlatGradReducer.arm_update; measured "
+                         "+0.7 %% at per-GPU batch 256, -1.8 %% at 32: not the default)")
     ap.add_argument("--rehearse-ddp", action="store_true",
                     help="single GPU only: run the N > 1 code path (one-rank RCCL group, bucketed async all-reduces from the "
                          "backward hooks, one-tile-per-workgroup NT launches) -- a rehearsal of the scaling run, not a metric")
@@ -170,7 +173,7 @@ def main():
     # is part of the step in every mode
     model.train(not args.no_dropout)
     store = model.store
-    reducer = FlatGradReducer(store, grad_dtype=args.ddp_grad_dtype)
+    reducer = FlatGradReducer(store, grad_dtype=args.ddp_grad_dtype, update_in_backward=args.optimizer_in_backward)
     if args.rehearse_ddp and world == 1:
         reducer.world = 2          # take the hook / bucket path; the sum over one rank is the identity
     reducer.attach()
@@ -193,10 +196,16 @@ def main():
 
     def step():
         store.zero_grad()
+        gs = ddp_scale if ddp_scale is not None else reducer.grad_scale
+        if reducer.update_in_backward:
+            # AdamW runs bucket by bucket on its own stream while backward still runs (ddp.FlatGradReducer.arm_update):
+            # every update of the step is issued and joined inside finish(), i.e. inside the timed region
+            reducer.arm_update(max_steps=max_steps, grad_scale=gs)
         loss = train_loss()
         loss.backward()
         reducer.finish()
-        store.adamw_step(max_steps=max_steps, grad_scale=ddp_scale if ddp_scale is not None else reducer.grad_scale)
+        if not reducer.update_in_backward:
+            store.adamw_step(max_steps=max_steps, grad_scale=gs)
         return loss
 
     for i in range(args.warmup):
@@ -436,6 +445,9 @@ def main():
                              "step (string metrics, m3ae_t5_mm_encoder_input.py:252-261) is EXCLUDED"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hip_streams": 2 if getattr(model.m3ae if args.head == "t5" else model, "two_streams", False) else 1,
+                       "optimizer": ("AdamW bucket by bucket on its own stream under backward (%d of %d buckets issued before "
+                                     "backward ended)" % (getattr(reducer, "updated_in_backward", 0), reducer.nb))
+                       if reducer.update_in_backward else "one AdamW pass after backward",
                        "dropout": ("p=0.1 at every dropout site of the model (train mode, as the reference)" if model.training
                                    else "off (eval-mode semantics)"), "weights": "random-init (synthetic, deterministic)",
                        **({"rehearsal": "N > 1 code path on one GPU (one-rank RCCL group); not the metric's configuration"}

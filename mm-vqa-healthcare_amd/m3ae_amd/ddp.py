@@ -38,10 +38,15 @@ from . import ops
 
 class FlatGradReducer:
     def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True, collective=None, world=None,
-                 tail_bytes=8 << 20, grad_dtype="fp32"):
+                 tail_bytes=8 << 20, grad_dtype="fp32", update_in_backward=False):
         """`collective(tensor) -> handle with .wait()` replaces `dist.all_reduce(SUM, async)` (tests: a summing stand-in
-        that plays the other ranks); `world` then names the emulated world size."""
+        that plays the other ranks); `world` then names the emulated world size.
+        `update_in_backward`: the optimizer runs bucket by bucket while backward still runs (see `arm_update`); also without
+        any data parallelism (world == 1: the buckets are then only the optimizer's work units)."""
         self.store, self.group, self.overlap = store, group, overlap
+        self.update_in_backward = update_in_backward
+        self._hyper = None          # this step's hyper-parameter record (arm_update); None: the caller steps the optimizer
+        self._opt_stream = None
         self.collective = collective
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         assert grad_dtype in ("fp32", "bf16")
@@ -75,18 +80,20 @@ class FlatGradReducer:
                     cuts.add(off)
                     hi = off
             i = j
-        params = [(off, p) for off, _, p in params]
         params.sort(key=lambda t: t[0])
         bounds = sorted(cuts)
         self.bounds = bounds
         self.nb = len(bounds) - 1
         self.bucket_of, self.pending0 = {}, [0] * self.nb
+        self.bucket_group = [0] * self.nb     # buckets never span optimizer groups
         bi = 0
-        for off, p in params:
+        for off, gi, p in params:
             while off >= bounds[bi + 1]:
                 bi += 1
             self.bucket_of[id(p)] = bi
+            self.bucket_group[bi] = gi
             self.pending0[bi] += 1
+        params = [(off, p) for off, _, p in params]
         self.expected = None   # reports per parameter per step, learned on the first step
         self.late = None
         self.glue = set()      # parameters that (also) receive a gradient through autograd's AccumulateGrad
@@ -118,16 +125,18 @@ class FlatGradReducer:
             self._bucket_streams = [set() for _ in range(self.nb)]
         self._bucket_events = [dict() for _ in range(self.nb)]
         self._multi_stream = bool(getattr(self.store, "streams", None))
+        self._complete = []        # (bucket, handle) in completion order, for the in-backward optimizer
+        self._updated = [False] * self.nb
 
     def attach(self):
-        ops.grad_ready_hook = self.on_grad_ready if self.world > 1 else None
+        ops.grad_ready_hook = self.on_grad_ready if (self.world > 1 or self.update_in_backward) else None
         if self.world > 1:
             # RCCL's kernels run next to backward and hold some CUs: the persistent NT kernel (static tile lists, one
             # workgroup per CU) would wait for them with a whole tile list in hand; every GEMM descriptor issued while the
             # reducer is attached asks for the one-tile-per-workgroup launch (restored by detach())
             self._saved_no_persist = ops.NT_NO_PERSISTENT
             ops.NT_NO_PERSISTENT = True
-        if self.world > 1 and not self._hooks:
+        if (self.world > 1 or self.update_in_backward) and not self._hooks:
             # a gradient that autograd itself accumulates (glue ops around the kernels, e.g. `x + positional_embedding`
             # in the masked-image pass) arrives at a time the kernels' reports say nothing about: such parameters keep
             # their bucket for finish(), even when they ALSO report in-place contributions
@@ -160,7 +169,9 @@ class FlatGradReducer:
         self.launched[bi] = True
         self._order.append(bi)
         a, b = self.bounds[bi], self.bounds[bi + 1]
-        if b > a:
+        if b > a and self.world <= 1:
+            self._complete.append((bi, None))       # nothing to exchange: the bucket is only the optimizer's work unit
+        elif b > a:
             # the bucket's gradients may have been written from more than one stream (the module's text half runs on a side
             # stream): the launching stream -- which the collective's own stream waits for -- first waits for the last report
             # of this bucket on every OTHER stream (an event recorded right behind that wgrad launch: nothing later on that
@@ -186,6 +197,41 @@ class FlatGradReducer:
             else:
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.handles.append(h)
+            self._complete.append((bi, h))
+
+    # ---- the optimizer inside backward -----------------------------------------------------------------------------------
+    def arm_update(self, **kw):
+        """Call before backward (every step): this step's optimizer hyper-parameters (arguments of ParamStore.begin_update).
+        From the second step on, a bucket's AdamW update is then issued on a separate stream as soon as the NEXT bucket has
+        completed -- at that point every backward kernel that reads the bucket's weights has been enqueued, and the update
+        waits for all of them (events on the compute streams) and for the bucket's all-reduce -- so the 9.9 GB of optimizer
+        traffic (HBM-bound, ~30 registers per lane: its waves fit beside the GEMMs' on a CU) runs under the compute-bound
+        rest of backward instead of after it.  `finish()` updates what is left, refreshes the transposed weight copies and
+        joins; the caller must NOT call the optimizer's step afterwards."""
+        assert self.update_in_backward
+        self._hyper = self.store.begin_update(**kw)
+
+    def _update_complete(self, keep_last):
+        todo = [(bi, h) for bi, h in self._complete if not self._updated[bi]]
+        if keep_last:
+            todo = todo[:-keep_last]
+        if not todo:
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream()
+        os_ = self._opt_stream
+        cur = torch.cuda.current_stream()
+        for st in {cur, *getattr(self.store, "streams", ())}:
+            os_.wait_event(st.record_event())       # everything enqueued so far on the compute streams
+        with torch.cuda.stream(os_):
+            for bi, h in todo:
+                a, b = self.bounds[bi], self.bounds[bi + 1]
+                if h is not None:
+                    h.wait()                        # stream-ordered behind the bucket's all-reduce
+                if self.grad_dtype == "bf16" and self._stage is not None and self.world > 1:
+                    self.store.grad[a:b].copy_(self._stage[a:b])
+                self.store.adamw_range(a, b, self.bucket_group[bi], self._hyper)
+                self._updated[bi] = True
 
     def _note_stream(self, bi):
         """A report for bucket `bi` on the current stream (called right behind the wgrad launch)."""
@@ -219,6 +265,8 @@ class FlatGradReducer:
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.overlap:
             self._launch(bi)
+            if self._hyper is not None:
+                self._update_complete(keep_last=1)
 
     def finish(self):
         """After backward: reduce every bucket not yet launched, wait for all, re-arm for the next step."""
@@ -237,10 +285,28 @@ class FlatGradReducer:
             if self.grad_dtype == "bf16" and self._stage is not None:
                 for bi in self._order:                # reduced bf16 -> the fp32 buffer the optimizer reads
                     a, b = self.bounds[bi], self.bounds[bi + 1]
-                    if b > a:
+                    if b > a and not self._updated[bi]:
                         self.store.grad[a:b].copy_(self._stage[a:b])
             if self.collective is None:
                 late_any = flag.item() > 0
+        if self._hyper is not None:
+            if self.world <= 1:
+                for bi in range(self.nb):
+                    self._launch(bi)
+            if self.grad_dtype == "bf16" and self._stage is not None and self.world > 1:
+                pass                                    # (copied above for the buckets not yet updated)
+            done_early = sum(self._updated)
+            cur = torch.cuda.current_stream()
+            if self._opt_stream is not None:
+                cur.wait_stream(self._opt_stream)       # updates issued during backward
+            for bi, _ in self._complete:                # the rest, here: backward is over, the collectives were waited for
+                if not self._updated[bi]:
+                    self.store.adamw_range(self.bounds[bi], self.bounds[bi + 1], self.bucket_group[bi], self._hyper)
+                    self._updated[bi] = True
+            assert all(self._updated[bi] or self.bounds[bi + 1] == self.bounds[bi] for bi in range(self.nb))
+            self.store.sync_shadows(cast=False)
+            self.updated_in_backward = done_early       # (tests / bench: how many buckets ran under backward)
+            self._hyper = None
         if late_any:
             name, self.late = self.late or "<on another rank>", None
             self.reset()

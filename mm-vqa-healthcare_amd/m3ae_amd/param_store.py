@@ -212,13 +212,11 @@ class ParamStore:
         pct = 1 - (step - warm) / (max_steps - warm)
         return ((lr_init - lr_end) * pct ** power + lr_end) / lr_init
 
-    @torch.no_grad()
-    def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None, group_lrs=None, betas=(0.9, 0.98), eps=1e-8,
-                   group_wds=None):
-        """One AdamW step over the six group segments (m3ae_utils.py:206; transformers-4.6.0 AdamW semantics,
-        betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step.
-        `group_lrs` (one learning rate per group, e.g. an Optimizer's param_groups after its scheduler stepped) overrides
-        the built-in schedule."""
+    def begin_update(self, max_steps=None, grad_scale=1.0, lr_factor=None, group_lrs=None, betas=(0.9, 0.98), eps=1e-8,
+                     group_wds=None):
+        """The host part of an optimizer step: per-group learning rates (built-in schedule unless given), step count.  Returns
+        the hyper-parameter record `adamw_range` takes; `adamw_step` = begin_update + adamw_range over the six segments, and
+        ddp.FlatGradReducer(update_in_backward=True) applies the same record bucket by bucket while backward still runs."""
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.grad)
             self.exp_avg_sq = torch.zeros_like(self.grad)
@@ -231,19 +229,34 @@ class ParamStore:
         if group_wds is None:
             group_wds = [wd for _, wd in hp]
         self.step_count += 1
-        L = _lib.lib()
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return dict(lrs=[float(x) for x in group_lrs], wds=[float(x) for x in group_wds], b1=float(betas[0]), b2=float(betas[1]),
+                    eps=float(eps), step=self.step_count, grad_scale=grad_scale)
+
+    @torch.no_grad()
+    def adamw_range(self, a, b, gi, hyper):
+        """The fused AdamW kernel over elements [a, b) of the flat buffers (inside optimizer group `gi`), on the current stream."""
+        if b <= a:
+            return
+        from . import ops as _ops
+        es = 4
+        sh = C.c_void_p(self.shadow.data_ptr() + a * 2) if self.shadow is not None else None
+        _lib.check(_lib.lib().m3ae_adamw(C.c_void_p(self.flat.data_ptr() + a * es), C.c_void_p(self.grad.data_ptr() + a * es),
+                                         C.c_void_p(self.exp_avg.data_ptr() + a * es),
+                                         C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, hyper["lrs"][gi],
+                                         hyper["b1"], hyper["b2"], hyper["eps"], hyper["wds"][gi], hyper["step"],
+                                         hyper["grad_scale"], _ops._stream()), "m3ae_adamw")
+
+    @torch.no_grad()
+    def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None, group_lrs=None, betas=(0.9, 0.98), eps=1e-8,
+                   group_wds=None):
+        """One AdamW step over the six group segments (m3ae_utils.py:206; transformers-4.6.0 AdamW semantics,
+        betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step.
+        `group_lrs` (one learning rate per group, e.g. an Optimizer's param_groups after its scheduler stepped) overrides
+        the built-in schedule."""
+        hyper = self.begin_update(max_steps, grad_scale, lr_factor, group_lrs, betas, eps, group_wds)
         for gi in range(6):
             a, b = self.segments[gi]
-            if b <= a:
-                continue
-            es = 4
-            sh = C.c_void_p(self.shadow.data_ptr() + a * 2) if self.shadow is not None else None
-            _lib.check(L.m3ae_adamw(C.c_void_p(self.flat.data_ptr() + a * es), C.c_void_p(self.grad.data_ptr() + a * es),
-                                    C.c_void_p(self.exp_avg.data_ptr() + a * es),
-                                    C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, float(group_lrs[gi]),
-                                    float(betas[0]), float(betas[1]), float(eps), float(group_wds[gi]), self.step_count,
-                                    grad_scale, s), "m3ae_adamw")
+            self.adamw_range(a, min(b, self.trainable_end), gi, hyper)
         self.sync_shadows(cast=False)
 
     def make_optimizer(self, max_steps=None):

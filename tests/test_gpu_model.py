@@ -763,6 +763,54 @@ def test_two_stream_schedule_equals_the_single_stream_step(task):
     m.two_streams = type(m).two_streams
 
 
+def test_optimizer_in_backward_equals_the_step_after_backward():
+    """`FlatGradReducer(update_in_backward=True)` without data parallelism (bench.py's default at N = 1): AdamW runs bucket by
+    bucket on its own stream as backward completes the buckets.  Same kernels over the same ranges with the same
+    hyper-parameters: after four steps at configs[1] dimensions (two HIP streams, dropout on) the fp32 masters, both moments,
+    the bf16 shadows and a transposed weight copy equal those of the plain zero_grad / backward / adamw_step loop up to
+    the run-to-run noise of the fp32 atomics, and most buckets were updated before backward ended."""
+    from m3ae_amd import ops
+    from m3ae_amd.ddp import FlatGradReducer
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    b = to_dev(synth.synthetic_batch(4, text_len=32, image_size=384, rank=0))
+
+    def run(in_backward):
+        m = build(cfg, torch.bfloat16)
+        m.set_task()
+        m.train()
+        red = FlatGradReducer(m.store, update_in_backward=in_backward)
+        assert red.world == 1
+        red.attach()
+        early = []
+        try:
+            for step in range(4):
+                m.store.zero_grad()
+                ops.set_dropout_seed(21 + step)
+                if in_backward:
+                    red.arm_update(max_steps=20)
+                m(b)["vqa_loss"].backward()
+                red.finish()
+                if in_backward:
+                    early.append(red.updated_in_backward)
+                else:
+                    m.store.adamw_step(max_steps=20)
+        finally:
+            red.detach()
+        st = m.store
+        wt = st._t_bufs[3][3].float().clone()
+        return st.flat.clone(), st.exp_avg.clone(), st.exp_avg_sq.clone(), st.shadow.float().clone(), wt, early, red.nb
+
+    f0, m0, v0, s0, t0, _, _ = run(False)
+    f1, m1, v1, s1, t1, early, nb = run(True)
+    assert early[0] == 0 and min(early[1:]) >= nb - 3, (early, nb)      # all but the last two (+ glue) under backward
+    init = build(cfg, torch.bfloat16).store.flat
+    moved = (f0 - init).double().norm().item()
+    assert (f1 - f0).double().norm().item() <= 1e-3 * moved
+    assert (m1 - m0).double().norm().item() <= 1e-3 * m0.double().norm().item()      # (atomics noise measured: 1.5e-4)
+    assert (v1 - v0).double().norm().item() <= 1e-3 * v0.double().norm().item()
+    assert (s1 - s0).abs().max().item() <= 1e-2 and (t1 - t0).abs().max().item() <= 1e-2
+
+
 def test_t5_head_training_mode_dropout_is_seeded_and_active():
     """configs[2] in train() mode: every HF-T5 dropout site (embeddings, attention weights, sub-layer outputs, inside the
     feed-forward, final norm) plus the frozen M3AE's own: reproducible from the seed, different across seeds / from eval."""
@@ -916,12 +964,12 @@ def test_grad_reducer_over_rccl_single_rank_group():
         cfg = tiny_config(compute_dtype="bf16")
         b = to_dev(tiny_batch())
 
-        def run(with_reducer):
+        def run(with_reducer, in_backward=False):
             m = build(cfg, torch.bfloat16)
             m.train()
             red = None
             if with_reducer:
-                red = FlatGradReducer(m.store, bucket_bytes=128 << 10)
+                red = FlatGradReducer(m.store, bucket_bytes=128 << 10, update_in_backward=in_backward)
                 red.world = 2                      # take the hook path; the group itself has one rank
                 red.attach()
             losses = []
@@ -929,24 +977,33 @@ def test_grad_reducer_over_rccl_single_rank_group():
                 for step in range(3):
                     m.store.zero_grad()
                     ops.set_dropout_seed(11 + step)
+                    if in_backward:                # AdamW bucket by bucket behind each bucket's all-reduce, under backward
+                        red.arm_update(max_steps=10, grad_scale=1.0)
                     loss = m.training_step(b)
                     loss.backward()
                     if red is not None:
                         early = sum(red.launched)
                         red.finish()
                         assert (early == 0) if step == 0 else (early >= red.nb // 2), (step, early, red.nb)
-                    m.store.adamw_step(max_steps=10, grad_scale=1.0)
+                        if in_backward:
+                            assert (red.updated_in_backward == 0) if step == 0 else (red.updated_in_backward >= red.nb // 2 - 1)
+                    if not in_backward:
+                        m.store.adamw_step(max_steps=10, grad_scale=1.0)
                     losses.append(loss.item())
             finally:
                 if red is not None:
                     red.detach()
-            return losses, m.store.flat.detach().clone()
+            return losses, m.store.flat.detach().clone(), m.store.shadow.detach().clone()
 
-        l0, p0 = run(False)
-        l1, p1 = run(True)
+        l0, p0, s0 = run(False)
+        l1, p1, s1 = run(True)
+        l2, p2, s2 = run(True, in_backward=True)
         # fp32 atomics in the split reductions: run-to-run differences of a few ulp are expected, nothing more
         assert np.allclose(l0, l1, rtol=1e-5, atol=0), (l0, l1)
         assert torch.allclose(p0, p1, rtol=0, atol=2e-5), float((p0 - p1).abs().max())
+        assert np.allclose(l0, l2, rtol=1e-5, atol=0), (l0, l2)
+        assert torch.allclose(p0, p2, rtol=0, atol=2e-5), float((p0 - p2).abs().max())
+        assert torch.allclose(s0.float(), s2.float(), rtol=0, atol=1e-3)
     finally:
         if own_group:
             dist.destroy_process_group()
