@@ -410,8 +410,10 @@ def run_dataset():
           "collate keys", res["roco_collate_keys"].tolist())
 
 
-def run_t5_base_dims():
-    """The generative head at T5-BASE dimensions (BASELINE configs[2]: d_model 768, 12 heads of 64, d_ff 3072; 2 + 2 layers are
+def run_t5_base_dims(which="base"):
+    """which = "large": the same recipe at T5-LARGE dimensions (BASELINE configs[4]: d_model 1024, 16 heads of 64, d_ff 4096) ->
+    t5large_dims.npz.
+    The generative head at T5-BASE dimensions (BASELINE configs[2]: d_model 768, 12 heads of 64, d_ff 3072; 2 + 2 layers are
     enough to exercise every dimension; vocabulary 1100).  The reference's wrapper hard-wires t5-small's width (512:
     m3ae_t5_mm_encoder_input.py:75,123-156), so this fixture comes from the class the reference instantiates -- HF
     T5ForConditionalGeneration -- driven directly with `inputs_embeds` / `labels`, with the deterministic weights of
@@ -420,7 +422,9 @@ def run_t5_base_dims():
     import torch.nn as nn
     from transformers import T5Config, T5ForConditionalGeneration
     VOC, L = 1100, 2
-    cfg = T5Config(vocab_size=VOC, d_model=768, d_kv=64, d_ff=3072, num_layers=L, num_decoder_layers=L, num_heads=12,
+    DM, DFF, NH = (768, 3072, 12) if which == "base" else (1024, 4096, 16)
+    tag = "t5base_dims" if which == "base" else "t5large_dims"
+    cfg = T5Config(vocab_size=VOC, d_model=DM, d_kv=64, d_ff=DFF, num_layers=L, num_decoder_layers=L, num_heads=NH,
                    dropout_rate=0.1, feed_forward_proj="relu", tie_word_embeddings=True, decoder_start_token_id=0,
                    pad_token_id=0, eos_token_id=1)
     cfg._attn_implementation = "eager"
@@ -443,8 +447,8 @@ def run_t5_base_dims():
     synth.fill_deterministic(m)
     m.t5.shared.weight.data.copy_(synth.det_normal("t5.shared.weight", m.t5.shared.weight.shape, std=0.02))
     m.eval()
-    x = synth.det_normal("t5base_dims.inputs_embeds", (2, 24, 768), std=0.5)
-    lab = synth.det_randint("t5base_dims.labels", 2, VOC, (2, 5), salt=9)
+    x = synth.det_normal(tag + ".inputs_embeds", (2, 24, DM), std=0.5)
+    lab = synth.det_randint(tag + ".labels", 2, VOC, (2, 5), salt=9)
     lab[0, -1] = 1
     lab[1, 3] = 1
     lab[1, 4] = 0          # a padded label position (ignored by the loss after the shift to -100 below)
@@ -460,8 +464,8 @@ def run_t5_base_dims():
             names.append(n)
             gn.append(p.grad.double().norm().item())
     res["grad_names"], res["grad_norm"] = np.array(names), np.array(gn)
-    np.savez_compressed(os.path.join(GOLD, "t5base_dims.npz"), **res)
-    print("[t5base_dims] loss", out.loss.item(), "with grad", len(names))
+    np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **res)
+    print("[" + tag + "] loss", out.loss.item(), "with grad", len(names))
 
 
 DEC_M3AE = dict(image_size=64, hidden_size=768, num_heads=12, num_top_layer=1, input_image_embed_size=128,
@@ -615,7 +619,7 @@ def run_mlm_collate():
 
 
 def main():
-    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "t5small", "decoder", "t5gen", "mlm", "dataset", "t5base"}
+    what = set(sys.argv[1:]) or {"tiny", "full", "large1", "pretrain", "t5", "t5small", "decoder", "t5gen", "mlm", "dataset", "t5base", "t5large"}
     os.makedirs(GOLD, exist_ok=True)
     if "tiny" in what:
         run_vqa("tiny_vqa", rs.reference_config(**TINY), TINY_ARCH, tiny_batch(), "full")
@@ -637,6 +641,8 @@ def main():
         run_dataset()
     if "t5base" in what:
         run_t5_base_dims()
+    if "t5large" in what:
+        run_t5_base_dims("large")
     if "large1" in what:
         # configs[4]'s tower dimensions at reduced depth: ONE ViT-L/16 block (width 1024, 16 heads, 512 x 512 = 1025 image
         # tokens), ONE RoBERTa-large layer (1024 / 16 heads / 4096), ONE co-attention layer pair (768 / 12 heads)

@@ -333,17 +333,21 @@ def test_full_t5_small_generative_head_against_reference_fixture(mode):
         assert abs(mine - r) <= tol * r + floor, (n, mine, r)
 
 
+@pytest.mark.parametrize("which", ["base", "large"])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_t5_base_dimensions_against_hf_fixture(mode):
-    """BASELINE configs[2] names a T5-BASE head: d_model 768, 12 heads of 64, d_ff 3072 (2 + 2 layers here, every dimension
-    exercised).  The reference's wrapper hard-wires t5-small's width, so the fixture (oracle/make_golden.py t5base) comes from
-    the class it instantiates -- HF T5ForConditionalGeneration -- with the deterministic weights under the reference's names and
-    its unfreeze recipe: encoder output, logits, loss and all 38 gradient norms, fp32 and bf16."""
+def test_t5_base_dimensions_against_hf_fixture(mode, which):
+    """BASELINE configs[2] names a T5-BASE head: d_model 768, 12 heads of 64, d_ff 3072; configs[4] a T5-LARGE head: d_model
+    1024, 16 heads of 64, d_ff 4096 (2 + 2 layers here, every dimension exercised).  The reference's wrapper hard-wires
+    t5-small's width, so the fixtures (oracle/make_golden.py t5base / t5large) come from the class it instantiates -- HF
+    T5ForConditionalGeneration -- with the deterministic weights under the reference's names and its unfreeze recipe: encoder
+    output, logits, loss and all 38 gradient norms, fp32 and bf16."""
     dtype = torch.float32 if mode == "fp32" else torch.bfloat16
-    dims = dict(d_model=768, d_kv=64, d_ff=3072, num_layers=2, num_decoder_layers=2, num_heads=12)
+    DM, DFF, NH = (768, 3072, 12) if which == "base" else (1024, 4096, 16)
+    tag = "t5base_dims" if which == "base" else "t5large_dims"
+    dims = dict(d_model=DM, d_kv=64, d_ff=DFF, num_layers=2, num_decoder_layers=2, num_heads=NH)
     m = _build_t5(mode, dtype, vocab=1100, dims=dims)
-    g = load_golden("t5base_dims.npz")
-    x = synth.det_normal("t5base_dims.inputs_embeds", (2, 24, 768), std=0.5).cuda().to(dtype)
+    g = load_golden(tag + ".npz")
+    x = synth.det_normal(tag + ".inputs_embeds", (2, 24, DM), std=0.5).cuda().to(dtype)
     labels = torch.from_numpy(g["labels"]).cuda()
     labels = labels.masked_fill(labels == 0, -100)
     m.store.zero_grad()
