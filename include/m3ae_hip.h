@@ -288,6 +288,11 @@ int m3ae_cast_transpose(const float* in, void* out, void* out_t, int64_t R, int6
 /* every weight unit in one launch: jobs_dev = device array of {const float* in; bf16* out_t; int64 R, C, first_tile}
  * (first_tile = running sum of ceil(R/32)*ceil(C/32)), total_tiles = the final running sum. */
 int m3ae_cast_transpose_batched(const void* jobs_dev, int njobs, int64_t total_tiles, void* stream);
+/* the same from bf16 sources (the weight shadows the optimizer kernel has just written): jobs_dev = device array of
+ * {const bf16* in; bf16* out_t; int64 R, C, first_tile} with first_tile = running sum of ceil(R/64)*ceil(C/64).
+ * (the reference has no counterpart: weights are used transposed-on-the-fly by torch.nn.functional.linear's backward,
+ * /root/reference/m3ae/modules/language_encoders/bert_model.py:419-441) */
+int m3ae_transpose_bf16_batched(const void* jobs_dev, int njobs, int64_t total_tiles, void* stream);
 /* elementwise: out = cast(in) (dtype_in -> dtype_out), n elements */
 int m3ae_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
 /* out = a + b (same dtype) */

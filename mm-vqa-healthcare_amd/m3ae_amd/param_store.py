@@ -169,8 +169,11 @@ class ParamStore:
             tab = np.zeros((len(self._t_bufs), 5), dtype=np.int64)
             first = 0
             for i, (u, rows, cols, t) in enumerate(self._t_bufs):
-                tab[i] = (u.data.data_ptr(), t.data_ptr(), rows, cols, first)
-                first += ((rows + 31) // 32) * ((cols + 31) // 32)
+                # source = the unit's bf16 shadow (same element offset as its fp32 master in the flat buffer)
+                off = (u.data.data_ptr() - self.flat.data_ptr()) // 4
+                assert 0 <= off < self.total
+                tab[i] = (self.shadow.data_ptr() + 2 * off, t.data_ptr(), rows, cols, first)
+                first += ((rows + 63) // 64) * ((cols + 63) // 64)
             self._t_tiles = first
             self._t_jobs = torch.from_numpy(tab).to(device)
         self.sync_shadows()
@@ -188,8 +191,8 @@ class ParamStore:
             _lib.check(L.m3ae_cast(C.c_void_p(self.flat.data_ptr()), C.c_void_p(self.shadow.data_ptr()), self.total,
                                    _lib.F32, _lib.BF16, s), "m3ae_cast")
         if self._t_bufs:
-            _lib.check(L.m3ae_cast_transpose_batched(C.c_void_p(self._t_jobs.data_ptr()), len(self._t_bufs),
-                                                     self._t_tiles, s), "m3ae_cast_transpose_batched")
+            _lib.check(L.m3ae_transpose_bf16_batched(C.c_void_p(self._t_jobs.data_ptr()), len(self._t_bufs),
+                                                     self._t_tiles, s), "m3ae_transpose_bf16_batched")
 
     # ---- optimizer -----------------------------------------------------------------------------------------
     def zero_grad(self):

@@ -815,6 +815,42 @@ def test_optimizer_in_backward_equals_the_step_after_backward():
     assert (s1 - s0).abs().max().item() <= 1e-2 and (t1 - t0).abs().max().item() <= 1e-2
 
 
+def test_transposed_weight_copies_equal_the_shadows_after_an_optimizer_step():
+    """The dgrad operands (`weight.m3ae_t`, [K][N] bf16) are rebuilt from the bf16 shadows by ONE table-driven launch
+    (`m3ae_transpose_bf16_batched`, 64 x 64 tiles, 16 B per lane; edge tiles and the 50265-row table element-wise): bit-equal to
+    the transposed shadow for every weight unit of the full-size model, after load and after an optimizer step."""
+    import time
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    m = build(cfg, torch.bfloat16)
+    st = m.store
+
+    def check():
+        n = 0
+        for u, rows, cols, t in st._t_bufs:
+            off = (u.data.data_ptr() - st.flat.data_ptr()) // 4
+            sh = st.shadow[off:off + rows * cols].view(rows, cols)
+            assert torch.equal(t, sh.t()), (rows, cols)
+            assert torch.equal(sh.float(), st.flat[off:off + rows * cols].view(rows, cols).to(torch.bfloat16).float())
+            n += 1
+        return n
+
+    assert check() >= 100
+    assert any(r % 64 or c % 64 for _, r, c, _ in st._t_bufs)      # the edge path is exercised
+    b = to_dev(synth.synthetic_batch(2, text_len=32, image_size=384, rank=0))
+    m.set_task()
+    m.train()
+    st.zero_grad()
+    m(b)["vqa_loss"].backward()
+    st.adamw_step(max_steps=10)
+    check()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        st.sync_shadows(cast=False)
+    torch.cuda.synchronize()
+    print(f"transposed copies of {len(st._t_bufs)} units: {(time.perf_counter() - t0) * 1e5:.0f} us per pass")
+
+
 def test_t5_head_training_mode_dropout_is_seeded_and_active():
     """configs[2] in train() mode: every HF-T5 dropout site (embeddings, attention weights, sub-layer outputs, inside the
     feed-forward, final norm) plus the frozen M3AE's own: reproducible from the seed, different across seeds / from eval."""
