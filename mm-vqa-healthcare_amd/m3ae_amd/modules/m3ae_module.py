@@ -159,7 +159,7 @@ class M3AETransformerSS(_Base):
 
     def _side(self):
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("M3AE_SIDE_PRIORITY", "0")))
+            self._side_stream = torch.cuda.Stream()   # default priority (a high-priority side stream measured the same)
             # gradients of directly-used leaves (e.g. the modality type embeddings) arrive from nodes of either stream: intended
             warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if warn_off is not None:
