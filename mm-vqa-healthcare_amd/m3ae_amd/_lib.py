@@ -3,7 +3,9 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libm3ae_hip.so")
+# M3AE_DIAGNOSTIC_LIB=1: load the timing-only / traced build of m3ae_amd/build.py (M3AE_EXTRA_HIPCC_FLAGS -> lib_diag/); tools only
+DIAGNOSTIC = os.environ.get("M3AE_DIAGNOSTIC_LIB", "") == "1"
+LIB_PATH = os.path.join(_PKG, "lib_diag" if DIAGNOSTIC else "lib", "libm3ae_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_TANH, ACT_RELU, ACT_MULAUX = 0, 1, 2, 3, 4, 5
@@ -123,6 +125,9 @@ def lib():
         # afterwards fails with hipErrorNoDevice (seen with __graft_entry__.build() followed by smoke() in one process).
         # Importing torch first makes its runtime the process's runtime.
         import torch  # noqa: F401
+        if DIAGNOSTIC:
+            import warnings
+            warnings.warn(f"m3ae_amd: loading the DIAGNOSTIC library {LIB_PATH} (timing-only builds may compute wrong results)")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported

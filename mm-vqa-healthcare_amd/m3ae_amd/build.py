@@ -2,6 +2,10 @@
 
     python -m m3ae_amd.build            # rebuild what changed
     python -m m3ae_amd.build --force
+
+Diagnostic / timing-only variants (M3AE_EXTRA_HIPCC_FLAGS=...) never overwrite the product library: they are built into
+lib_diag/ (own objects, own .so) and are only loaded when the caller exports M3AE_DIAGNOSTIC_LIB=1 (m3ae_amd/_lib.py).
+The flag string is part of the staleness key of either directory (lib*/.build_flags).
 """
 import concurrent.futures as cf
 import os
@@ -12,11 +16,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(PKG))
 CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 INC = os.path.join(ROOT, "include")
-OUT_DIR = os.path.join(PKG, "lib")
+EXTRA = os.environ.get("M3AE_EXTRA_HIPCC_FLAGS", "").split()
+OUT_DIR = os.path.join(PKG, "lib_diag" if EXTRA else "lib")
 LIB = os.path.join(OUT_DIR, "libm3ae_hip.so")
+STAMP = os.path.join(OUT_DIR, ".build_flags")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
-         f"-I{INC}", f"-I{CSRC}"] + os.environ.get("M3AE_EXTRA_HIPCC_FLAGS", "").split()
+         f"-I{INC}", f"-I{CSRC}"] + EXTRA
 
 
 def _stale(target, deps):
@@ -28,6 +34,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
+    key = " ".join(FLAGS)
+    old = open(STAMP).read() if os.path.exists(STAMP) else None
+    if old != key:
+        # objects built with other flags are stale whatever their mtime; a pre-stamp tree (old is None) may hold ANY build
+        force = True
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INC, "m3ae_hip.h")]
     objs, jobs = [], []
@@ -56,6 +67,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + out)
         if verbose:
             print("[m3ae build] linked", LIB, flush=True)
+    with open(STAMP, "w") as f:
+        f.write(key)
     return LIB
 
 
