@@ -33,6 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: see 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+DOM_KINDS = ("gemm:mfma_nt_pp2", "gemm:mfma_nt_pp")   # ops.PROFILE record kinds of the ping-pong NT GEMM kernels
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 FWD_GFLOP_PER_SAMPLE = 183.8
 STEP_GFLOP_PER_SAMPLE = 551.3  # fwd + bwd
@@ -114,6 +115,7 @@ def main():
                     help="skip the secondary line (configs[2]: frozen M3AE + t5-base head at per-GPU batch 64, run as a child "
                          "process after the main measurement; N = 1 default run only)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size bf16-vs-reference-fixture error report")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode semantics (A/B of the dropout cost)")
     ap.add_argument("--ddp-grad-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="gradient bucket dtype of the data-parallel all-reduce (bf16: half the bytes over xGMI, ddp.py)")
@@ -213,6 +215,30 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done, loss {loss.item():.4f}")
 
+    # data-parallel runs: what RCCL sees and what the links deliver, recorded BEFORE the timed region so that the scaling curve can
+    # be read against it (DESIGN.md 7's prediction): a 20-iteration all-reduce of 64 MiB fp32 (one gradient bucket)
+    dist_info = None
+    if world > 1 or args.rehearse_ddp:
+        probe = torch.ones(16 * 2 ** 20, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(probe)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 20
+        wsz = dist.get_world_size()
+        dist_info = {"backend": dist.get_backend(), "world_size_seen_by_rccl": wsz,
+                     "allreduce_probe": {"bytes": probe.numel() * 4, "iters": 20, "ms": round(ar_ms, 4),
+                                         "algbw_GBps": round(probe.numel() * 4 / (ar_ms * 1e-3) / 1e9, 1),
+                                         "busbw_GBps": round(probe.numel() * 4 / (ar_ms * 1e-3) / 1e9 * 2 * (wsz - 1) / max(wsz, 1), 1)},
+                     "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+        del probe
+        reducer.exposed_ms = []       # finish() appends the time its caller's stream waited for the collectives of a step
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -236,12 +262,19 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
+    if dist_info is not None and getattr(reducer, "exposed_ms", None):
+        ex = sorted(reducer.exposed_ms[-args.steps:])
+        dist_info["exposed_comm_ms_per_step"] = {"median": round(ex[len(ex) // 2], 3), "max": round(ex[-1], 3),
+                                                 "how": "HIP events on the caller's stream around FlatGradReducer.finish()'s waits "
+                                                        "for the step's bucket all-reduces (what backward did not cover), this rank"}
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     final_loss = loss.item()
     log(f"timed region: {ms_per_step:.2f} ms/step, {value:.1f} pairs/s")
 
     roofline, xattn, kern_table = None, None, None
+    if dist_info is None:
+        dist_info = {"world_size_seen_by_rccl": 1, "note": "single process, no process group"}
     if rank == 0 and not args.no_roofline:
         log("roofline leg")
         reducer.detach()
@@ -260,7 +293,7 @@ def main():
         alone = None
         if getattr(m3r, "two_streams", False):
             m3r.two_streams = False      # the same launches with nothing beside them: the kernel's own rate
-            ra = [(k, d, a_, b_) for k, d, a_, b_ in profiled_steps() if k == "gemm:mfma_nt_pp"]
+            ra = [(k, d, a_, b_) for k, d, a_, b_ in profiled_steps() if k in DOM_KINDS]
             m3r.two_streams = True
             ms_a = sum(a_.elapsed_time(b_) for _, _, a_, b_ in ra)
             fl_a = sum(2.0 * d[0] * d[1] * d[2] * d[3] for _, d, _, _ in ra)
@@ -294,12 +327,14 @@ def main():
                 f"{2.0 * M_ * N_ * K_ * n_ / (ms_ * 1e-3) / 1e12:7.1f} TF/s, total {ms_ / 2:7.2f} ms/step")
         kern_table = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
                       for k, v in agg.items() if v[1] > 0}
-        dom = "gemm:mfma_nt_pp"  # the dominant kernel of the step: gemm_nt_pp(_persistent)_kernel, all epilogue instantiations
+        # the dominant kernel of the step: gemm_nt_pp2_kernel (round 4; gemm_nt_pp(_persistent)_kernel before), all epilogue classes
+        dom = max(DOM_KINDS, key=lambda k_: agg.get(k_, [0, 0.0, 0.0])[1])
         if dom in agg:
             n, ms, fl = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
             # data-parallel runs use the one-tile-per-workgroup launch of the same kernel body (ddp.FlatGradReducer.attach)
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp_persistent_kernel" if world == 1 else "gemm_nt_pp_kernel",
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_pp2_kernel" if dom.endswith("pp2") else
+                        ("gemm_nt_pp_persistent_kernel" if world == 1 else "gemm_nt_pp_kernel"),
                         "achieved": round(ach, 1),
                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "traffic": None, "launches": n // 2, "avg_launch_ms": round(ms / n, 4),
@@ -393,6 +428,33 @@ def main():
                                                "the side stream beside the image queries of the same layer"}
         reducer.attach()
 
+    parity = None
+    if rank == 0 and world == 1 and args.head == "cls" and args.arch == "base" and not args.no_parity:
+        # the kernels just timed (bf16 storage, MFMA, fused cross-attention) against the reference fixture at FULL size: configs[1]
+        # dimensions, B = 2, eval mode; tests/golden/full_vqa.npz holds the unmodified reference's logits / loss / gradient norms
+        gpath = os.path.join(ROOT, "tests", "golden", "full_vqa.npz")
+        if os.path.exists(gpath):
+            import numpy as np
+            from m3ae_amd.parity import parity_report
+            log("parity leg (full size, B = 2, bf16 MFMA path vs the reference fixture)")
+            pm = M3AETransformerSS(finetune_vqa_rad_config(compute_dtype="bf16"))
+            synth.fill_deterministic(pm)
+            pm.finalize(dev, torch.bfloat16)
+            pm.eval()
+            pb = to_dev(synth.synthetic_batch(2, text_len=32, image_size=384, vocab_size=50265, rank=0), dev)
+            old_rule = ops.XATTN_TRAIN_MIN_BATCH
+            parity = {"what": "bf16 MFMA path vs tests/golden/full_vqa.npz (reference-generated: configs[1] dimensions, B = 2, eval "
+                              "mode, one forward + backward); tolerance north_star states for fp32 parity mode: logits rtol 1e-3 -- "
+                              "the bf16 path is reported as observed, not held to it (DESIGN.md 4)"}
+            for label, rule in (("fused_cross_attention", 0), ("batch_rule_default", old_rule)):
+                ops.XATTN_TRAIN_MIN_BATCH = rule
+                r = parity_report(pm, np.load(gpath, allow_pickle=False), pb)
+                parity[label] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in r.items()
+                                 if k not in ("p99_rel_err_param_grad_norms",)}
+            ops.XATTN_TRAIN_MIN_BATCH = old_rule
+            del pm, pb
+            torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import m3ae_oracle as O
@@ -436,7 +498,7 @@ def main():
             log("secondary line: " + label + " (child process)")
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", *extra,
                    "--steps", str(min(args.steps, 8)), "--warmup", str(min(args.warmup, 2)), "--no-roofline", "--no-cpu-baseline",
-                   "--no-secondary"] + (["--no-dropout"] if args.no_dropout else [])
+                   "--no-secondary", "--no-parity"] + (["--no-dropout"] if args.no_dropout else [])
             try:
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
                 rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
@@ -484,6 +546,7 @@ def main():
             if args.head == "cls" else None,
             "final_loss": round(final_loss, 4), "step_ms": step_stats,
             "roofline": roofline, "cross_attention_fwd": xattn, "kernels": kern_table, "cpu_baseline": cpu,
+            "parity": parity, "distributed": dist_info,
             "secondary": secondary,
             "notes": {"optimizer": "AdamW update rule restated from transformers==4.6.0 (third party, not installable here): "
                                    "group membership / lr / weight decay / schedule are pinned by reference fixtures, the "

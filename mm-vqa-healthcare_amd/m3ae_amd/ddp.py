@@ -84,7 +84,7 @@ class FlatGradReducer:
         bounds = sorted(cuts)
         self.bounds = bounds
         self.nb = len(bounds) - 1
-        self.bucket_of, self.pending0 = {}, [0] * self.nb
+        self.bucket_of = {}
         self.bucket_group = [0] * self.nb     # buckets never span optimizer groups
         bi = 0
         for off, gi, p in params:
@@ -92,9 +92,9 @@ class FlatGradReducer:
                 bi += 1
             self.bucket_of[id(p)] = bi
             self.bucket_group[bi] = gi
-            self.pending0[bi] += 1
         params = [(off, p) for off, _, p in params]
         self.expected = None   # reports per parameter per step, learned on the first step
+        self.exposed_ms = None  # a list when the caller wants finish()'s exposed-communication times (bench.py)
         self.late = None
         self.glue = set()      # parameters that (also) receive a gradient through autograd's AccumulateGrad
         self._params = [p for _, p in params]
@@ -209,6 +209,10 @@ class FlatGradReducer:
         rest of backward instead of after it.  `finish()` updates what is left, refreshes the transposed weight copies and
         joins; the caller must NOT call the optimizer's step afterwards."""
         assert self.update_in_backward
+        # the early update of a bucket assumes every later reader of its weights is ordered behind events already recorded: true when
+        # the GEMMs read the bf16 shadows / transposed copies the update rewrites LAST (finish()), not the fp32 masters.  A "late
+        # contribution" error raised by this mode leaves the parameters partially stepped (the buckets updated so far).
+        assert self.store.compute_dtype == torch.bfloat16, "update_in_backward needs the bf16 shadow / transposed-copy layout"
         self._hyper = self.store.begin_update(**kw)
 
     def _update_complete(self, keep_last):
@@ -279,9 +283,15 @@ class FlatGradReducer:
                 # waiting in their next collective.  One more (4-byte) all-reduce in the same queue as the buckets.
                 flag = torch.tensor([1.0 if late_any else 0.0], device=self.store.grad.device)
                 self.handles.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+            ev = None
+            if self.exposed_ms is not None:             # bench.py: how long the caller's stream waits for collectives backward did not cover
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self.handles:
                 if h is not None:
                     h.wait()
+            if ev is not None:
+                ev[1].record()
             if self.grad_dtype == "bf16" and self._stage is not None:
                 for bi in self._order:                # reduced bf16 -> the fp32 buffer the optimizer reads
                     a, b = self.bounds[bi], self.bounds[bi + 1]
@@ -289,12 +299,13 @@ class FlatGradReducer:
                         self.store.grad[a:b].copy_(self._stage[a:b])
             if self.collective is None:
                 late_any = flag.item() > 0
+            if ev is not None:
+                ev[1].synchronize()
+                self.exposed_ms.append(ev[0].elapsed_time(ev[1]))
         if self._hyper is not None:
             if self.world <= 1:
                 for bi in range(self.nb):
                     self._launch(bi)
-            if self.grad_dtype == "bf16" and self._stage is not None and self.world > 1:
-                pass                                    # (copied above for the buckets not yet updated)
             done_early = sum(self._updated)
             cur = torch.cuda.current_stream()
             if self._opt_stream is not None:

@@ -35,7 +35,17 @@ class _JoinAtEndFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         main, side = ctx.streams
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+
+        def join():
+            # the in-place weight gradients are invisible to autograd's own end-of-backward synchronisation: whoever reads
+            # store.grad next does so on the stream that is current NOW (normally `main`; it may differ from the forward's)
+            main.wait_stream(side)
+            cur = torch.cuda.current_stream()
+            if cur != main:
+                cur.wait_stream(main)
+                cur.wait_stream(side)
+
+        torch.autograd.Variable._execution_engine.queue_callback(join)
         return g, None, None
 
 

@@ -96,6 +96,11 @@ def _p(t):
 def _need_cuda(t):
     if not t.is_cuda:
         raise _lib.M3AEHipError("m3ae_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+    # _stream() hands out the raw current stream of ONE device (the first one an op ran on: one process drives one GPU): a
+    # tensor of another device would be launched on that device's stream handle
+    if _dev_index is not None and t.device.index != _dev_index:
+        raise _lib.M3AEHipError(f"m3ae_amd ops were first used on cuda:{_dev_index}; got a tensor on {t.device} "
+                                f"(one process drives one GPU: call torch.cuda.set_device before the first op)")
 
 
 def compute_weight(w):
@@ -278,6 +283,9 @@ class LinearFn(torch.autograd.Function):
         dres = dy if ctx.has_res else None
         dz = act_bwd(dy2, pre, ctx.act) if ctx.act != ACT_NONE else dy2
         dextra = None
+        dx = None
+        if ctx.x_needs:   # before the weight gradient reports the parameter: an optimizer-in-backward update of this weight's
+            dx = mm_dgrad(dz, ctx.weight, alpha=ctx.alpha).view(ctx.x_shape)   # bucket is then ordered behind this read of it
         if ctx.extra_needs:
             mm_wgrad(dz, x2, ctx.ldx, ctx.weight, alpha=ctx.alpha)
             dextra = torch.empty(N, dtype=torch.float32, device=dz.device)
@@ -288,9 +296,6 @@ class LinearFn(torch.autograd.Function):
                 _done(ctx.bias)
         else:
             mm_wgrad(dz, x2, ctx.ldx, ctx.weight, ctx.bias, alpha=ctx.alpha)
-        dx = None
-        if ctx.x_needs:
-            dx = mm_dgrad(dz, ctx.weight, alpha=ctx.alpha).view(ctx.x_shape)
         return (dx, dres, dextra, None, None, None, None) + (None,) * ctx.n_anchor
 
 

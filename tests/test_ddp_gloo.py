@@ -172,4 +172,4 @@ def test_bucket_boundaries_are_parameter_aligned_and_cover_buffer():
     assert red.bounds[0] == 0 and red.bounds[-1] == store.trainable_end
     offs = {store.offset[id(p)] for _, p in named}
     assert all(b in offs or b == store.trainable_end for b in red.bounds)
-    assert sum(red.pending0) == len(named)
+    assert len(red.bucket_of) == len(named) and all(0 <= b < red.nb for b in red.bucket_of.values())

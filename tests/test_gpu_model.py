@@ -222,6 +222,31 @@ def test_large_tower_dims_reduced_depth_against_reference(mode):
         assert abs(gn - float(g["global_grad_norm"])) < 5e-2 * float(g["global_grad_norm"]), (gn, float(g["global_grad_norm"]))
 
 
+# Observed on MI355X at round 4 (tools/parity_full.py, profiles/r04_parity_full_size_observed.log), configs[1] dimensions, B = 2,
+# eval mode, bf16 MFMA path against the reference fixture: max |dlogits| 0.0222 / 0.0232 (fused cross-attention / composition;
+# |logits| <= 1.91), loss relative error 1.0e-5 / 2.2e-4, global gradient norm 1.0e-3 / 1.7e-3, the 404 per-parameter gradient
+# norms above 1 % of the largest: worst 2.6e-3 / 5.5e-3, median over all 663: 1.2e-3 / 1.7e-3.  Bounds = 2 x the observed values.
+BF16_FULL_SIZE_BOUNDS = {"max_abs_dlogits": 0.046, "loss_rel_err": 4.5e-4, "global_grad_norm_rel_err": 3.4e-3,
+                         "max_rel_err_large_param_grad_norms": 1.1e-2, "median_rel_err_param_grad_norms": 3.5e-3}
+
+
+@pytest.mark.parametrize("cross_rule", ["fused", "default"])
+def test_full_size_bf16_observed_errors_within_twice_the_recorded_ones(cross_rule):
+    """The path bench.py times (bf16 storage, MFMA kernels, fused cross-attention under either training rule) at FULL size
+    against the reference fixture: the observed errors are printed (pytest -s) and held to 2 x the values recorded above --
+    a 10 % regression of a fused kernel does not pass (VERDICT r3, weak #1)."""
+    from m3ae_amd import ops
+    from m3ae_amd.parity import parity_report
+    if cross_rule == "default":
+        ops.XATTN_TRAIN_MIN_BATCH = 96          # the autouse fixture restores it
+    m = build(finetune_vqa_rad_config(compute_dtype="bf16"), torch.bfloat16)
+    rep = parity_report(m, load_golden("full_vqa.npz"), to_dev(full_batch()))
+    print(f"\n[bf16 full-size parity, cross-attention rule {cross_rule}] " + ", ".join(
+        f"{k} {rep[k]:.3e}" for k in BF16_FULL_SIZE_BOUNDS) + f"; worst large parameter: {rep['worst_large_param']}")
+    for k, bound in BF16_FULL_SIZE_BOUNDS.items():
+        assert rep[k] <= bound, (k, rep[k], bound, rep)
+
+
 @pytest.mark.parametrize("cross_rule", ["fused", "default"])
 def test_full_size_bf16_step_and_optimizer(cross_rule):
     """configs[1] perf mode: one full training step (fwd + bwd + fused AdamW); loss close to the fp32 reference,
@@ -768,7 +793,7 @@ def test_two_stream_schedule_equals_the_single_stream_step(task):
 
 
 def test_optimizer_in_backward_equals_the_step_after_backward():
-    """`FlatGradReducer(update_in_backward=True)` without data parallelism (bench.py's default at N = 1): AdamW runs bucket by
+    """`FlatGradReducer(update_in_backward=True)` without data parallelism (an opt-in of bench.py: --optimizer-in-backward): AdamW runs bucket by
     bucket on its own stream as backward completes the buckets.  Same kernels over the same ranges with the same
     hyper-parameters: after four steps at configs[1] dimensions (two HIP streams, dropout on) the fp32 masters, both moments,
     the bf16 shadows and a transposed weight copy equal those of the plain zero_grad / backward / adamw_step loop up to

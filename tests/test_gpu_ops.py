@@ -66,7 +66,7 @@ def test_gemm_nt_bias_act_residual(M, N, K, dtype):
         assert ops.last_gemm_path() == expect
 
 
-@pytest.mark.parametrize("variant", [0, 4, 7])
+@pytest.mark.parametrize("variant", [0, 4, 7, 9])
 def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     """The MFMA NT kernel variants against the generic kernel on identical bf16 inputs, ragged M / N tails."""
     from m3ae_amd import _lib
@@ -75,18 +75,18 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
                     (2308, 2304, 768)]:
         x, w = rnd(M, K, dtype=torch.bfloat16, seed=5), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=6)
         y1, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32)
-        assert ops.last_gemm_path() in ("mfma_nt", "mfma_nt_pp")
+        assert ops.last_gemm_path() in ("mfma_nt", "mfma_nt_pp", "mfma_nt_pp2")
         y2, _ = ops.mm_nt(x, K, M, w, out_dtype=torch.float32, force_generic=True)
         assert ops.last_gemm_path() == "generic"
         close(y1, y2, 1e-5, 1e-5, msg=f"{M}x{N}x{K}")
     ops.GEMM_NT_VARIANT = -1
 
 
-@pytest.mark.parametrize("variant", [7, 8, -1])
+@pytest.mark.parametrize("variant", [7, 8, 9, 10, -1])
 @pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul", "dropout+res"])
 def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant, kind):
-    """The step's dominant kernel -- gemm_nt_pp_kernel (7) and its persistent form (8; what the auto rule (-1) picks from
-    512 tiles on) -- against an INDEPENDENT fp32 torch reference on the same bf16-rounded operands, every epilogue class,
+    """The step's dominant kernel -- gemm_nt_pp2_kernel (round 4: 9, its persistent launch 10; what the auto rule (-1) picks for
+    large shapes) and its predecessors gemm_nt_pp_kernel (7) / persistent (8) -- against an INDEPENDENT fp32 torch reference on the same bf16-rounded operands, every epilogue class,
     at a ragged shape with >= 512 tiles (36965 x 3072 x 768: 145 x 12 = 1740 tiles, last row tile 101 rows)."""
     from m3ae_amd import _lib
     L = _lib.lib()
@@ -121,7 +121,7 @@ def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant,
             ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, residual=aux, dropout=(0.1, 4242))
             ref = (pre + b) * keep.float() / 0.9 + aux.float()
             assert 0.88 < keep.float().mean().item() < 0.92
-        assert ops.last_gemm_path() == "mfma_nt_pp"
+        assert ops.last_gemm_path() == ("mfma_nt_pp" if variant in (7, 8) else "mfma_nt_pp2")
         close(y, ref, 1e-2, 2e-2, msg=f"variant {variant} {kind}")
     finally:
         ops.GEMM_NT_VARIANT = -1
@@ -644,7 +644,7 @@ def test_gemm_epilogue_dropout_after_activation_and_in_dgrad(dtype):
 @pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul"])
 def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     """Every NT kernel the auto path or a tuning key can select for large shapes -- 256x256 2-stage (4), ping-pong (7), its
-    persistent form (8, >= 512 tiles) -- accumulates in the same order: on the
+    persistent form (8, >= 512 tiles), the second-generation kernel of round 4 (9, persistent launch 10, auto -1) -- accumulates in the same order: on the
     path's own large shapes and epilogue classes the bf16 outputs are identical, ragged row tail included."""
     from m3ae_amd import _lib
     L = _lib.lib()
@@ -655,7 +655,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     aux = rnd(M, N, dtype=torch.bfloat16, seed=24)
     outs = {}
     try:
-        for v in (4, 7, 8):
+        for v in (4, 7, 8, 9, 10, -1):
             ops.GEMM_NT_VARIANT = v
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             extra = None
@@ -669,8 +669,8 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
             else:
                 ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_MULAUX)
             outs[v] = (y, extra, ops.last_gemm_path())
-        assert outs[8][2] == "mfma_nt_pp"
-        for v in (7, 8):
+        assert outs[8][2] == "mfma_nt_pp" and outs[9][2] == outs[10][2] == outs[-1][2] == "mfma_nt_pp2"
+        for v in (7, 8, 9, 10, -1):
             assert torch.equal(outs[v][0].view(torch.int16), outs[4][0].view(torch.int16)), (kind, v)
             if outs[4][1] is not None:
                 assert torch.equal(outs[v][1].view(torch.int16), outs[4][1].view(torch.int16)), (kind, v, "derivative")
