@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--optimizer-in-backward", action="store_true",
                     help="AdamW bucket by bucket on its own stream under backward (ddp.FlatGradReducer.arm_update; measured "
                          "+0.7 %% at per-GPU batch 256, -1.8 %% at 32: not the default)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as ONE hipGraph (m3ae_amd/graph.py: dropout salt and AdamW hyper-parameters in device memory). "
+                         "auto = off: on ROCm 7.2 a replay of this ~1000-node graph costs the host MORE than the eager launches and "
+                         "serialises the two HIP streams (profiles/r04_hipgraph_replay_B32_measured.log)")
     ap.add_argument("--rehearse-ddp", action="store_true",
                     help="single GPU only: run the N > 1 code path (one-rank RCCL group, bucketed async all-reduces from the "
                          "backward hooks, one-tile-per-workgroup NT launches) -- a rehearsal of the scaling run, not a metric")
@@ -210,10 +214,32 @@ def main():
             store.adamw_step(max_steps=max_steps, grad_scale=gs)
         return loss
 
+    graphed, graph_note = None, "eager launches"
+    want_graph = args.graph == "on"   # "auto" = off: measured on ROCm 7.2 a replay of the ~1000-node two-branch graph costs the
+    # host 35 ms and serialises the two streams (44 ms/step against 34.6 eager at per-GPU batch 32, profiles/r04_hipgraph_replay_B32_measured.log)
+    if want_graph and (world > 1 or args.rehearse_ddp or args.optimizer_in_backward):
+        want_graph, graph_note = False, "eager launches (graph replay is single-GPU only: the data-parallel step exchanges buckets from backward hooks)"
     for i in range(args.warmup):
         loss = step()
         torch.cuda.synchronize()
         log(f"warm-up step {i} done, loss {loss.item():.4f}")
+    if want_graph:
+        from m3ae_amd.graph import GraphedStep
+        reducer.detach()
+        try:
+            graphed = GraphedStep(model, batch, max_steps=max_steps)
+            loss = graphed.step()          # capture + first replay (a real step)
+            torch.cuda.synchronize()
+            log(f"step captured as one hipGraph, loss {loss.item():.4f}")
+            eager_step = step
+            step = graphed.step
+            loss = step()
+            torch.cuda.synchronize()
+            graph_note = "ONE hipGraph replay per step (m3ae_amd/graph.py; per-replay dropout salt and AdamW hyper-parameters in device memory)"
+        except Exception as e:  # noqa: BLE001 -- keep measuring: the eager step is the fallback, and the line says so
+            log(f"graph capture failed ({e!r}): eager step")
+            graphed, graph_note = None, f"eager launches (graph capture failed: {e!r})"
+            reducer.attach()
 
     # data-parallel runs: what RCCL sees and what the links deliver, recorded BEFORE the timed region so that the scaling curve can
     # be read against it (DESIGN.md 7's prediction): a 20-iteration all-reduce of 64 MiB fp32 (one gradient bucket)
@@ -531,6 +557,7 @@ def main():
                              "step (string metrics, m3ae_t5_mm_encoder_input.py:252-261) is EXCLUDED"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hip_streams": 2 if getattr(model.m3ae if args.head == "t5" else model, "two_streams", False) else 1,
+                       "launch": graph_note,
                        "optimizer": ("AdamW bucket by bucket on its own stream under backward (%d of %d buckets issued before "
                                      "backward ended)" % (getattr(reducer, "updated_in_backward", 0), reducer.nb))
                        if reducer.update_in_backward else "one AdamW pass after backward",

@@ -26,7 +26,11 @@ extern "C" {
 
 /* 2: m3ae_gemm_desc grew `preact_grad` and `launch_flags` (round 2), m3ae_xattn_desc grew `launch_flags` and dir 1 takes
  *    probs == NULL (forward-only calls); m3ae_desc_sizes() lets a binding check its struct layouts at load time. */
-#define M3AE_ABI_VERSION 2
+/* 3: dropout salt (round 4).  m3ae_gemm_desc / m3ae_attn_desc / m3ae_xattn_desc grew `dropout_salt`, m3ae_layernorm_bwd_drop and
+ *    m3ae_dropout take it as an argument: an optional DEVICE pointer to a 32-bit value the kernels fold into the mask key, so a
+ *    step captured in a hipGraph (kernel arguments frozen, seeds included) draws new masks at every replay once the caller bumps
+ *    that value; m3ae_adamw takes `hyper_dev` (device {lr, step size} of the step) for the same reason. */
+#define M3AE_ABI_VERSION 3
 
 enum { M3AE_F32 = 0, M3AE_BF16 = 1 };
 enum { M3AE_ACT_NONE = 0, M3AE_ACT_GELU = 1, M3AE_ACT_QUICKGELU = 2, M3AE_ACT_TANH = 3, M3AE_ACT_RELU = 4,
@@ -84,6 +88,7 @@ typedef struct {
     int32_t launch_flags;  /* M3AE_GEMM_NO_PERSISTENT: never take the persistent (one workgroup per CU, static tile lists)
                             * form of the NT kernel -- for callers that run collectives next to the GEMMs (RCCL kernels
                             * hold CUs; a persistent workgroup that finds none starts after another has walked its list) */
+    const void* dropout_salt; /* NULL, or device uint32: folded into the dropout mask key at kernel entry (ABI 3, above) */
 } m3ae_gemm_desc;
 enum { M3AE_GEMM_NO_PERSISTENT = 1 };
 /* Diagnostic selectors in launch_flags (0 in the product path = kernel chosen by shape): tests pin the kernel variants
@@ -129,6 +134,7 @@ typedef struct {
      * after the softmax normaliser is taken; mask = counter hash of (seed, ((b*H+h)*Lq+q)*Lk+k), regenerated in bwd */
     float dropout_p;
     uint64_t dropout_seed;
+    const void* dropout_salt; /* as m3ae_gemm_desc.dropout_salt */
 } m3ae_attn_desc;
 int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward);
 int m3ae_attn_fwd(const m3ae_attn_desc* d, void* stream);
@@ -191,6 +197,7 @@ typedef struct {
     float* ws_vec;                /* fp32 [3 * B * H * T], T = min(Lq, Lk) text tokens */
     float* ws_ln;                 /* fp32 [2 * m3ae_layernorm_bwd_blocks(B*Lq) * D] */
     int32_t launch_flags;         /* M3AE_XATTN_*: per-call launch policy (the library keeps no state) */
+    const void* dropout_salt;     /* as m3ae_gemm_desc.dropout_salt: both dropout sites of the sub-block */
 } m3ae_xattn_desc;
 enum { M3AE_XATTN_NO_PERSISTENT = 1,  /* the internal m3ae_gemm calls never take the persistent NT kernel (callers that run
                                        * collectives next to the step: see m3ae_gemm_desc.launch_flags) */
@@ -226,15 +233,15 @@ int m3ae_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
  * whose output was dropped before the residual add (post-LN BERT blocks), produced without an extra pass over dx. */
 int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                             const float* rstd, void* dx, void* dx_drop, float dropout_p, uint64_t dropout_seed,
-                            float* dgamma, float* dbeta, float* workspace, int64_t M, int64_t D, int dtype,
-                            void* stream);
+                            const void* dropout_salt, float* dgamma, float* dbeta, float* workspace, int64_t M, int64_t D,
+                            int dtype, void* stream);
 /* out = dropout(x) on a dense [rows][cols] array with the library's counter-hash mask (forward and backward are
  * the same map).  Every dropout site of the library -- this call, the GEMM epilogue (rows = M, cols = N), the
  * LayerNorm backward second output, and attention probabilities (rows = (b*H + h)*Lq + q, cols = Lk) -- uses the mask
  * index row * ld + col with ld = cols rounded up to a multiple of 4, so a mask exported here (keep_mask, uint8
  * [rows][cols], optional) is the mask those kernels apply for the same (p, seed). */
 int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t rows, int64_t cols, float p, uint64_t seed,
-                 int dtype, void* stream);
+                 const void* salt, int dtype, void* stream);
 
 /* out[n] (+)= sum_m x[m][n]  (bias gradients; x has row stride ldx elements). */
 int m3ae_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
@@ -281,7 +288,10 @@ int m3ae_xent(const void* logits, const int64_t* labels, float* loss, void* d_lo
  * copy used by the forward pass.
  */
 int m3ae_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
-               float beta2, float eps, float wd, int64_t step, float grad_scale, void* stream);
+               float beta2, float eps, float wd, int64_t step, float grad_scale, const float* hyper_dev, void* stream);
+/* hyper_dev (ABI 3): NULL, or a device pointer to {lr, lr * sqrt(1 - beta2^step) / (1 - beta1^step)} of THIS step: the kernel then
+ * takes both from there instead of from `lr` / `step` (a hipGraph-captured step replays with frozen arguments; the caller
+ * uploads the two floats per group before every replay). */
 
 /* bf16 [R, C] <- fp32 [R, C] cast; and the transposed bf16 copy out_t [C, R] (dgrad operand). either may be NULL */
 int m3ae_cast_transpose(const float* in, void* out, void* out_t, int64_t R, int64_t C, void* stream);

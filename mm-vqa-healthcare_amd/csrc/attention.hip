@@ -273,6 +273,7 @@ DEVINL AttnBlock attn_block() {
 // unrolled softmax into 16 basic blocks and fence the MFMA / VALU interleave for the eval-mode instances too.
 template <int NQ, bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP) ? 4 : 2) void attn_fwd_coop_kernel(AttnArgs a) {
+    if (DROP) drop_resolve(a.drop);
     constexpr int BUF = RIMG + TILE_LDS;  // K row image + V tr image
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP
 
 template <bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
+    if (DROP) drop_resolve(a.drop);
     constexpr int BUF = RIMG + TILE_LDS + RIMG;  // K row image, K tr image, V row image
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
 
 template <bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) {
+    if (DROP) drop_resolve(a.drop);
     // Q row, Q tr, dO row, dO tr images + the tile's 32 log-sum-exp and 32 delta values (staged with the tile by
     // threads 0..15: as per-lane global loads inside the tile they cost 13 % of the kernel -- timing ablation)
     constexpr int IMG = 2 * (RIMG + TILE_LDS), BUF = IMG + 256;
@@ -760,7 +763,7 @@ AttnArgs to_args(const m3ae_attn_desc& d) {
     a.d_o = (const bf16_t*)d.d_o; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
     a.delta = d.delta; a.d_pos_bias = d.d_pos_bias;
     a.has_drop = d.dropout_p > 0.f;
-    a.drop = make_drop(d.dropout_p, d.dropout_seed);
+    a.drop = make_drop(d.dropout_p, d.dropout_seed, d.dropout_salt);
     return a;
 }
 
@@ -807,7 +810,7 @@ extern "C" int m3ae_attn_fwd(const m3ae_attn_desc* dp, void* stream) {
     int rc = attn_f32_scores(d, S, s);
     if (rc) return rc;
     if (d.dropout_p > 0.f &&  // P is [B H Lq][Lk]: rows x cols of the same mask index the bf16 kernels use
-        (rc = m3ae_dropout(S, S, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+        (rc = m3ae_dropout(S, S, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, d.dropout_salt, M3AE_F32, stream)))
         return rc;
     const int64_t QK = d.Lq * d.Lk;
     m3ae_gemm_desc g = bgemm(d);
@@ -842,7 +845,7 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     float* dS = P + d.B * d.H * QK;
     int rc = attn_f32_scores(d, P, s);
     if (rc) return rc;
-    if (drop && (rc = m3ae_dropout(P, P, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+    if (drop && (rc = m3ae_dropout(P, P, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, d.dropout_salt, M3AE_F32, stream)))
         return rc;  // dV below needs the dropped P that multiplied V in the forward pass
     // dP = dO . V^T
     m3ae_gemm_desc g = bgemm(d);
@@ -861,7 +864,7 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
     const int64_t rows = d.B * d.H * d.Lq;
     if (drop) {  // the softmax backward needs the un-dropped P and dP wrt it
         if ((rc = attn_f32_scores(d, P, s))) return rc;
-        if ((rc = m3ae_dropout(dS, dS, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, M3AE_F32, stream)))
+        if ((rc = m3ae_dropout(dS, dS, nullptr, d.B * d.H * d.Lq, d.Lk, d.dropout_p, d.dropout_seed, d.dropout_salt, M3AE_F32, stream)))
             return rc;
     }
     hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, P, dS, rows, d.Lk);

@@ -193,17 +193,25 @@ DEVINL uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-struct DropState { uint32_t key_lo, key_hi, thr; float inv_keep; };
-static inline DropState make_drop(float p, uint64_t seed) {
+// salt (ABI 3): optional DEVICE pointer to a 32-bit per-step value folded into the key by drop_resolve() at kernel entry.  A step
+// captured in a hipGraph replays with the SAME kernel arguments (seeds included); the caller bumps *salt between replays and every
+// site draws a fresh mask.  NULL (eager runs: the host draws a fresh seed per site and step) leaves the key as it is.
+struct DropState { uint32_t key_lo, key_hi, thr; float inv_keep; const uint32_t* salt; };
+static inline DropState make_drop(float p, uint64_t seed, const void* salt = nullptr) {
     DropState d;
+    d.salt = (const uint32_t*)salt;
     d.key_lo = (uint32_t)seed; d.key_hi = (uint32_t)(seed >> 32);
     double t = (double)p * 4294967296.0;
     d.thr = t >= 4294967295.0 ? 4294967295U : (uint32_t)t;
     d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }
-DEVINL DropState make_drop_dev(float p, uint64_t seed) {  // same as make_drop, callable on the device
+DEVINL void drop_resolve(DropState& d) {   // once per kernel, before the first hash (wave-uniform scalar load)
+    if (d.salt) d.key_hi += *d.salt * 0x85EBCA6BU;
+}
+DEVINL DropState make_drop_dev(float p, uint64_t seed, const void* salt = nullptr) {  // same as make_drop, callable on the device
     DropState d;
+    d.salt = (const uint32_t*)salt;
     d.key_lo = (uint32_t)seed; d.key_hi = (uint32_t)(seed >> 32);
     const float t = p * 4294967296.0f;
     d.thr = t >= 4294967040.0f ? 4294967295U : (uint32_t)t;

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(m3ae_gemm_desc d) {
         }
     }
 
-    const DropState drop = make_drop_dev(d.dropout_p, d.dropout_seed);
+    DropState drop = make_drop_dev(d.dropout_p, d.dropout_seed, d.dropout_salt);
+    drop_resolve(drop);
     TC* C = (TC*)d.C + coff;
     TC* P = d.preact ? (TC*)d.preact + coff : nullptr;
     const TC* R = d.residual ? (const TC*)d.residual + coff : nullptr;

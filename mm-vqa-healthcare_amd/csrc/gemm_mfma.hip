@@ -28,6 +28,7 @@ using namespace m3g;
 // (loads stay in flight across the raw s_barrier).
 template <int BM_, int BN_, int BKT, int NST, int WM, int EPI>
 __global__ __launch_bounds__((BM_ / WM) * (BN_ / 64) * 64, 2) void gemm_nt_bf16_kernel(MfmaArgs a) {
+    if (a.has_drop) drop_resolve(a.drop);
     constexpr int WAVES_N = BN_ / 64, NWAVES = (BM_ / WM) * WAVES_N, MI = WM / 16;
     constexpr int A_BYTES = BM_ * BKT * 2, ST_BYTES = (BM_ + BN_) * BKT * 2;
     constexpr int A_SEGS = A_BYTES / 1024 / NWAVES, B_SEGS = BN_ * BKT * 2 / 1024 / NWAVES;  // DMA pieces per wave
@@ -312,6 +313,7 @@ DEVINL void nt_stage_contig(const bf16_t* G, int64_t ld, int64_t row0, int64_t n
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(MfmaArgs a) {
+    if (a.has_drop) drop_resolve(a.drop);
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -459,6 +461,7 @@ __device__ uint64_t g_nt_trace[1024 * 2 * 8];   // [block][wave row][fragment re
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_persistent_kernel(MfmaArgs a) {
+    if (a.has_drop) drop_resolve(a.drop);
     constexpr int CK = 32, NW = 8, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -661,9 +664,13 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const bool persist_ok = t256 >= 512;   // the persistent form pays from two full rounds on (+1..3 %)
         // second-generation ping-pong kernel (gemm_nt_pp2.hip): -2.2 % against the persistent kernel below over the step's eleven
         // shape / epilogue classes at per-GPU batch 256, -3.6 % against the one-tile-per-workgroup form data-parallel runs take
-        // (profiles/r04_nt_pp2_second_ab.log).  Its persistent and one-tile-per-workgroup launches measure the same (7032 / 7040 us
-        // over the eleven), so the plain launch is taken everywhere: no static tile lists that start late beside RCCL's kernels.
-        if (big && a.rows_epi && a.K >= 256) { g_last_path = "mfma_nt_pp2"; return launch_nt_pp2(a, EPI, false, s); }
+        // (profiles/r04_nt_pp2_second_ab.log).  Its persistent launch (grid = CUs) is 0.9 % faster than one workgroup per tile on
+        // the kernels alone and 0.8 % on the whole step (1303 vs 1293 pairs/s, profiles/r04_nt_pp2_stagger_and_persistent_ab.log);
+        // data-parallel runs (M3AE_GEMM_NO_PERSISTENT) take the per-tile launch: static tile lists start late beside RCCL's kernels.
+        if (big && a.rows_epi && a.K >= 256) {
+            g_last_path = "mfma_nt_pp2";
+            return launch_nt_pp2(a, EPI, persist_ok && !a.no_persist, s);
+        }
         if (big && persist_ok && !a.no_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
@@ -698,7 +705,7 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
         a.col_group = g_nt_col_group > 0 ? g_nt_col_group : (tiles_n <= 9 ? tiles_n : 6);
     }
     a.has_drop = d.dropout_p > 0.f;
-    a.drop = make_drop(d.dropout_p, d.dropout_seed);
+    a.drop = make_drop(d.dropout_p, d.dropout_seed, d.dropout_salt);
     a.no_persist = (d.launch_flags & M3AE_GEMM_NO_PERSISTENT) ? 1 : 0;
     a.nt_variant = ((d.launch_flags >> 8) & 0xf) - 1;
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;

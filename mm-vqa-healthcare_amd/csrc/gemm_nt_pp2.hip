@@ -100,6 +100,7 @@ DEVINL void epi_finish(const MfmaArgs& a, float* slab, int lane, int64_t m_base,
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
+    if (a.has_drop) drop_resolve(a.drop);
     constexpr int CK = 32, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES, RING = 4 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -115,6 +116,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
     const unsigned lds_wave = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)wave * 1024u;
     unsigned v = blockIdx.x;
     if (v >= total) return;
+#ifdef M3AE_EXP_PP2_STAGGER   // timing experiment (tools/nt_exp.sh): de-phase the workgroups' tile boundaries by quarter tiles
+    {
+        const unsigned k = (blockIdx.x >> 3) & 3u;   // same XCD (blockIdx & 7), neighbouring workgroups differ
+        const uint64_t t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (uint64_t)k * M3AE_EXP_PP2_STAGGER) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     unsigned tm, tn;
     nt_tile_coords(xcd_remap(v, total), tiles_m, tiles_n, tm, tn, (unsigned)a.col_group);
     int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;

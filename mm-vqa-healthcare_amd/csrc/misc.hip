@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* x, const int64_t* la
 
 // ---- AdamW (transformers 4.6.0 semantics) -----------------------------------------------------------------
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* shadow, int64_t n4, float lr,
-                             float b1, float b2, float eps, float wd, float step_size, float grad_scale) {
+                             float b1, float b2, float eps, float wd, float step_size, float grad_scale,
+                             const float* hyper_dev) {
+    if (hyper_dev) { lr = hyper_dev[0]; step_size = hyper_dev[1]; }   // a captured step: this step's values come from device memory
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
         const f32x4 gg = ((const f32x4*)g)[i];
@@ -464,6 +466,7 @@ __global__ void act_bwd_kernel(const T* dy, const T* x, T* dx, int64_t n, int ac
 }
 template <typename T>
 __global__ void dropout_kernel(const T* x, T* out, uint8_t* keep, int64_t n, int64_t cols, int64_t ld, DropState ds) {
+    drop_resolve(ds);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols;
         const bool k = drop_keep(ds, (uint64_t)(r * ld + (i - r * cols)));
@@ -623,14 +626,14 @@ extern "C" int m3ae_xent(const void* logits, const int64_t* labels, float* loss,
 
 extern "C" int m3ae_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                           float beta1, float beta2, float eps, float wd, int64_t step, float grad_scale,
-                          void* stream) {
+                          const float* hyper_dev, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || step <= 0) return M3AE_ERR_ARG;
     if (n % 4 != 0 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return M3AE_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4)), dim3(EW_BLOCK), 0, s, p, g, m, v, (bf16_t*)shadow_bf16, n / 4,
-                       lr, beta1, beta2, eps, wd, step_size, grad_scale);
+                       lr, beta1, beta2, eps, wd, step_size, grad_scale, hyper_dev);
     return hip_launch_status();
 }
 
@@ -691,11 +694,11 @@ extern "C" int m3ae_act_bwd(const void* dy, const void* x_pre, void* dx, int64_t
     return hip_launch_status();
 }
 extern "C" int m3ae_dropout(const void* x, void* out, uint8_t* keep_mask, int64_t rows, int64_t cols, float p,
-                            uint64_t seed, int dtype, void* stream) {
+                            uint64_t seed, const void* salt, int dtype, void* stream) {
     if (rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f || (!out && !keep_mask) || (out && !x)) return M3AE_ERR_ARG;
     const int64_t n = rows * cols;
     hipStream_t s = (hipStream_t)stream;
-    const DropState ds = make_drop(p, seed);
+    const DropState ds = make_drop(p, seed, salt);
     DT_SWITCH(dtype, hipLaunchKernelGGL(dropout_kernel<T>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, (const T*)x, (T*)out,
                                         keep_mask, n, cols, drop_ld(cols), ds));
     return hip_launch_status();

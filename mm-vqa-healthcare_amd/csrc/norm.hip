@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, const T* x, co
                                                      const float* mean_i, const float* rstd_i, T* dx, const T* dx_add,
                                                      float* part, int64_t M, int D, int act, int rms, T* dx_drop,
                                                      DropState drop) {
+    if (dx_drop) drop_resolve(drop);
     extern __shared__ float red[];  // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -465,13 +466,13 @@ extern "C" int m3ae_layernorm_bwd(const void* dy, const void* x, const float* ga
 
 extern "C" int m3ae_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* beta,
                                        const float* mean, const float* rstd, void* dx, void* dx_drop, float dropout_p,
-                                       uint64_t dropout_seed, float* dgamma, float* dbeta, float* workspace, int64_t M,
-                                       int64_t D, int dtype, void* stream) {
+                                       uint64_t dropout_seed, const void* dropout_salt, float* dgamma, float* dbeta,
+                                       float* workspace, int64_t M, int64_t D, int dtype, void* stream) {
     if (!dy || !x || !gamma || !rstd || !dx || !dx_drop || !workspace || M <= 0) return M3AE_ERR_ARG;
     if (D % 4 != 0 || D > 2048) return M3AE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     int nblk = (int)m3ae_layernorm_bwd_blocks(M);
-    const DropState drop = make_drop(dropout_p, dropout_seed);
+    const DropState drop = make_drop(dropout_p, dropout_seed, dropout_salt);
     auto run = [&]() -> int {
         if (dtype == M3AE_F32)
             DISPATCH_CPL(launch_bwd, float, dy, x, gamma, beta, mean, rstd, dx, nullptr, workspace, &nblk, M, (int)D, 0, 0, s, dx_drop, drop);

@@ -128,6 +128,7 @@ template <int WN, class RowPtr> DEVINL void slab_store_bf16(const char* slab, in
 //   staged piece) and branches compile out of the staging code, which sits in every chunk's read phase.
 template <int BM, int BN, int WAVES_M, int NSLOT, int NLOAD, int AFORM, int BFORM, int EPI, int GEN>
 __global__ __launch_bounds__(NLOAD ? 768 : 512, NLOAD ? 3 : 2) void xg_kernel(XgArgs a) {
+    if (a.has_drop) drop_resolve(a.drop);
     constexpr int WAVES_N = 8 / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NJ = WN / 16;
     constexpr int NST = NLOAD ? NLOAD : 8;   // waves that issue the LDS-DMA pieces
     // pieces per staging wave and chunk; an operand with fewer pieces than staging waves (BM = 64 with 8 of them) is staged by
@@ -1108,7 +1109,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             a.colbias = d.key_mask; a.cb_sb = I;
             a.rowsum_out = drop ? d.rowsum : nullptr;
             a.n_valid = I;
-            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn, d.dropout_salt);
             a.H = H; a.Lq = T; a.drop_ld = (int)drop_ld(I);
             XCHK((launch_xg<128, 640, 2, 3, 0, FORM_K, FORM_K, XE_SOFTMAXROW>(a, B, s)));
         }
@@ -1136,7 +1137,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
         m3ae_gemm_desc o = g;
         o.M = (int64_t)B * T; o.N = D; o.K = D;
         o.A = d.ctx; o.a_sm = D; o.B = d.wo; o.b_sn = D; o.C = d.s; o.c_sm = D; o.bias = d.bo; o.residual = d.x;
-        o.dropout_p = d.dropout_p; o.dropout_seed = d.seed_hidden;
+        o.dropout_p = d.dropout_p; o.dropout_seed = d.seed_hidden; o.dropout_salt = d.dropout_salt;
         XCHK(m3ae_gemm(&o, stream));
     } else {
         const int I = Lq, T = Lk, R = H * T;
@@ -1186,7 +1187,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
             f.X = (const bf16_t*)d.x; f.Kp = Kp; f.Vp = Vp; f.colbias = d.colbias; f.bo = d.bo;
             f.S = (bf16_t*)d.s; f.P = (bf16_t*)d.probs; f.Pd = drop ? (bf16_t*)d.probs_drop : nullptr;
             f.B = B; f.I = I; f.D = D; f.H = H;
-            f.has_drop = drop; f.drop_a = make_drop(d.dropout_p, d.seed_attn); f.drop_h = make_drop(d.dropout_p, d.seed_hidden);
+            f.has_drop = drop; f.drop_a = make_drop(d.dropout_p, d.seed_attn, d.dropout_salt); f.drop_h = make_drop(d.dropout_p, d.seed_hidden, d.dropout_salt);
             f.drop_ld = (int)drop_ld(T);
             // (LayerNorm inside this launch -- single-pass statistics in the pass epilogues, a cross-wave exchange, a normalise
             // pass over the tile's own stores -- was built and measured in round 3: kernel 340 -> 487 us against 89 us for the
@@ -1203,7 +1204,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
                 a.C2 = drop ? (bf16_t*)d.probs_drop : nullptr;
                 a.alpha = 1.0f;
                 a.colbias = d.colbias; a.cb_sb = R;
-                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn, d.dropout_salt);
                 a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T);
                 XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_SOFTMAX32>(a, B, s)));
             }
@@ -1215,7 +1216,7 @@ extern "C" int m3ae_xattn_fwd(const m3ae_xattn_desc* dp, void* stream) {
                 a.C = (bf16_t*)d.s; a.ldc = D;
                 a.bias = d.bo;
                 a.residual = (const bf16_t*)d.x;
-                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden);
+                a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_hidden, d.dropout_salt);
                 XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_T, XE_DENSE>(a, B, s)));
             }
         }
@@ -1253,7 +1254,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
     const void* dsd = d.ws_ds;
     if (drop) {
         XCHK(m3ae_layernorm_bwd_drop(d.d_out, d.s, d.ln_g, d.ln_b, d.mean, d.rstd, d.ws_ds, d.ws_dsd, d.dropout_p, d.seed_hidden,
-                                     d.g_ln_g, d.g_ln_b, d.ws_ln, Mq, D, M3AE_BF16, stream));
+                                     d.dropout_salt, d.g_ln_g, d.g_ln_b, d.ws_ln, Mq, D, M3AE_BF16, stream));
         dsd = d.ws_dsd;
     } else {
         XCHK(m3ae_layernorm_bwd(d.d_out, d.s, d.ln_g, d.ln_b, d.mean, d.rstd, d.ws_ds, nullptr, d.g_ln_g, d.g_ln_b, d.ws_ln, Mq, D,
@@ -1284,7 +1285,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
             a.M = I; a.N = R; a.K = D;
             a.C = dS; a.ldc = R; a.c_sb = (int64_t)I * R;
             a.P = (const bf16_t*)d.probs;
-            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+            a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn, d.dropout_salt);
             a.drop_mode = 1; a.H = H; a.Lq = I; a.drop_ld = (int)drop_ld(T); a.tkeys = T;
             // a wave's columns must hold whole heads: 96 = 3 x 32 (384-wide tile) or 64 (256-wide tile)
             if (T == 32) XCHK((launch_xg<128, 384, 2, 4, 4, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
@@ -1411,7 +1412,7 @@ extern "C" int m3ae_xattn_bwd(const m3ae_xattn_desc* dp, void* stream) {
         a.M = R; a.N = 640; a.K = D;
         a.C = dS; a.ldc = 640; a.c_sb = (int64_t)R * 640;
         a.P = (const bf16_t*)d.probs; a.delta = delta; a.radd = radd;
-        a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn);
+        a.has_drop = drop; a.drop = make_drop(d.dropout_p, d.seed_attn, d.dropout_salt);
         a.drop_mode = 0; a.H = H; a.Lq = T; a.drop_ld = (int)drop_ld(I);
         XCHK((launch_xg<128, 640, 2, 3, 0, FORM_K, FORM_K, XE_DSOFT>(a, B, s)));
     }

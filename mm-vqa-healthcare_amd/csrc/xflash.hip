@@ -52,6 +52,7 @@ __device__ uint64_t g_xf_trace2[4096 * 3 * 4];
 
 template <int BM, int R, int T>
 __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
+    if (a.has_drop) { drop_resolve(a.drop_a); drop_resolve(a.drop_h); }
     constexpr int WM = BM / 2, WN1 = R / 4, MI = WM / 16, NJ1 = WN1 / 16, TG = T / 16;
     constexpr int A1_BYTES = BM * 64, SLOT1 = (BM + R) * 64;
     constexpr int NSLOT1 = XF_LDS / SLOT1 >= 5 ? 5 : 3, DEPTH1 = NSLOT1 - 1;

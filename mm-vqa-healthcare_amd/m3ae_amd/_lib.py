@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("dtype_a", i32), ("dtype_b", i32), ("dtype_c", i32),
         ("alpha", f32), ("accumulate", i32), ("bias", vp), ("act", i32), ("preact", vp), ("residual", vp),
         ("dact_aux", vp), ("dact", i32), ("force_generic", i32), ("a_rowsum", vp),
-        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("preact_grad", i32), ("launch_flags", i32),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("preact_grad", i32), ("launch_flags", i32), ("dropout_salt", vp),
     ]
 
 
@@ -36,7 +36,7 @@ class AttnDesc(C.Structure):
         ("key_mask", vp), ("pos_bias", vp), ("scale", f32), ("causal", i32),
         ("lse", vp), ("lse_stride", i64), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
         ("d_o", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp), ("d_pos_bias", vp),
-        ("dropout_p", f32), ("dropout_seed", C.c_uint64),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("dropout_salt", vp),
     ]
 
 
@@ -52,13 +52,13 @@ class XattnDesc(C.Structure):
         ("d_out", vp), ("dx", vp), ("dy", vp),
         ("g_wq", vp), ("g_wkv", vp), ("g_wo", vp), ("g_bq", vp), ("g_bkv", vp), ("g_bo", vp), ("g_ln_g", vp), ("g_ln_b", vp),
         ("ws_ds", vp), ("ws_dsd", vp), ("ws_dscores", vp), ("ws_dprime", vp), ("ws_dproj", vp), ("ws_dz", vp), ("ws_dctx", vp),
-        ("ws_vec", vp), ("ws_ln", vp), ("launch_flags", i32),
+        ("ws_vec", vp), ("ws_ln", vp), ("launch_flags", i32), ("dropout_salt", vp),
     ]
 
 
 GEMM_NO_PERSISTENT = 1                            # m3ae_gemm_desc.launch_flags
 XATTN_NO_PERSISTENT, XATTN_LEGACY_CHAIN = 1, 2    # m3ae_xattn_desc.launch_flags
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 _SIGS = {
@@ -77,8 +77,8 @@ _SIGS = {
     "m3ae_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, C.c_int, C.c_int, vp]),
     "m3ae_layernorm_bwd_blocks": (i64, [i64]),
     "m3ae_layernorm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
-    "m3ae_layernorm_bwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp, vp, vp, i64, i64, C.c_int, vp]),
-    "m3ae_dropout": (C.c_int, [vp, vp, vp, i64, i64, f32, C.c_uint64, C.c_int, vp]),
+    "m3ae_layernorm_bwd_drop": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp, vp, vp, vp, i64, i64, C.c_int, vp]),
+    "m3ae_dropout": (C.c_int, [vp, vp, vp, i64, i64, f32, C.c_uint64, vp, C.c_int, vp]),
     "m3ae_colsum": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
     "m3ae_roberta_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
     "m3ae_roberta_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp]),
@@ -88,7 +88,7 @@ _SIGS = {
     "m3ae_vit_tokens_bwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, C.c_int, vp]),
     "m3ae_bce_logits": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, C.c_int, vp]),
     "m3ae_xent": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, f32, C.c_int, vp]),
-    "m3ae_adamw": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+    "m3ae_adamw": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp, vp]),
     "m3ae_cast_transpose": (C.c_int, [vp, vp, vp, i64, i64, vp]),
     "m3ae_cast_transpose_batched": (C.c_int, [vp, C.c_int, i64, vp]),
     "m3ae_transpose_bf16_batched": (C.c_int, [vp, C.c_int, i64, vp]),

@@ -25,7 +25,7 @@ SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
 NT_NO_PERSISTENT = os.environ.get("M3AE_NT_NO_PERSISTENT", "0") == "1"   # (set by ddp.FlatGradReducer.attach; the env default is for A/B runs)
 # diagnostic per-call kernel selectors (m3ae_gemm_desc.launch_flags; -1 / 0 = by shape): tests compare kernel variants bit for
 # bit, tools time them; the product path never sets them
-GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = -1, -1, 0
+GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = int(os.environ.get("M3AE_GEMM_NT_VARIANT", -1)), -1, 0   # (env: A/B runs of tools)
 
 
 def _gemm_flags():
@@ -58,6 +58,16 @@ _drop_base, _drop_ctr = 0x5EED, 0
 def set_dropout_seed(seed):
     global _drop_base, _drop_ctr
     _drop_base, _drop_ctr = int(seed) & 0xFFFFFFFF, 0
+
+
+# Dropout salt (ABI 3): a device uint32 every dropout kernel folds into its mask key.  None in eager runs (the host draws a fresh
+# seed per site and step); graph.GraphedStep points it at its per-replay counter while it captures, so the frozen seeds of the
+# captured launches still give new masks at every replay.
+DROPOUT_SALT = None
+
+
+def _salt():
+    return None if DROPOUT_SALT is None else C.c_void_p(DROPOUT_SALT.data_ptr())
 
 
 def next_dropout_seed():
@@ -141,6 +151,7 @@ def gemm(a, a_sm, a_sk, b, b_sk, b_sn, c, c_sm, M, N, K, *, alpha=1.0, accumulat
         d.a_rowsum = a_rowsum.data_ptr()
     if dropout is not None and dropout[0] > 0:
         d.dropout_p, d.dropout_seed = dropout
+        d.dropout_salt = _salt()
     e0 = _prof_begin()
     check(_lib.lib().m3ae_gemm(C.byref(d), _stream()), "m3ae_gemm")
     if e0 is not None:
@@ -440,7 +451,7 @@ def ln_bwd_raw(dy, x2, ln, mean, rstd, dx_add=None, act=ACT_NONE, rms=False, dro
         assert dx_add is None and act == ACT_NONE and not rms
         dxd = torch.empty_like(x2)
         check(L.m3ae_layernorm_bwd_drop(_p(dy), _p(x2), _p(ln.weight), _p(ln.bias), _p(mean), _p(rstd), _p(dx), _p(dxd),
-                                        drop[0], drop[1], _p(gg), _p(gb), _p(ws), M, D, _dt(x2), _stream()),
+                                        drop[0], drop[1], _salt(), _p(gg), _p(gb), _p(ws), M, D, _dt(x2), _stream()),
               "m3ae_layernorm_bwd_drop")
         if train:
             _done(ln.weight)
@@ -501,6 +512,7 @@ def attn_forward(q, k, v, heads, key_mask=None, pos_bias=None, scale=None, causa
     d = _attn_desc(B, heads, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, lse, lse_stride, _dt(q))
     if dropout is not None and dropout[0] > 0:
         d.dropout_p, d.dropout_seed = dropout
+        d.dropout_salt = _salt()
     ws = _attn_ws(d, False, q.device)
     e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_fwd(C.byref(d), _stream()), "m3ae_attn_fwd")
@@ -531,6 +543,7 @@ def attn_backward(q, k, v, o, lse, do, dq, dk, dv, heads, key_mask=None, pos_bia
     d.d_pos_bias = d_pos_bias.data_ptr() if d_pos_bias is not None else None
     if dropout is not None and dropout[0] > 0:
         d.dropout_p, d.dropout_seed = dropout
+        d.dropout_salt = _salt()
     ws = _attn_ws(d, True, q.device)
     e0 = _prof_begin()
     check(_lib.lib().m3ae_attn_bwd(C.byref(d), _stream()), "m3ae_attn_bwd")
@@ -632,6 +645,7 @@ def _xattn_desc(h2, B, L, other2, Lo, mask, P, pdrop, seeds):
     d.ln_g, d.ln_b, d.ln_eps = P.ln.weight.data_ptr(), P.ln.bias.data_ptr(), P.ln.eps
     if pdrop > 0:
         d.dropout_p, d.seed_attn, d.seed_hidden = pdrop, seeds[0], seeds[1]
+        d.dropout_salt = _salt()
     d.launch_flags = (_lib.XATTN_NO_PERSISTENT if NT_NO_PERSISTENT else 0) | (_lib.XATTN_LEGACY_CHAIN if XATTN_LEGACY_CHAIN else 0)
     return d
 
@@ -938,7 +952,7 @@ def _drop_raw(x2, drop):
         return x2
     x2 = x2.contiguous()
     out = torch.empty_like(x2)
-    check(_lib.lib().m3ae_dropout(_p(x2), _p(out), None, x2.shape[0], x2.shape[1], drop[0], drop[1], _dt(x2), _stream()),
+    check(_lib.lib().m3ae_dropout(_p(x2), _p(out), None, x2.shape[0], x2.shape[1], drop[0], drop[1], _salt(), _dt(x2), _stream()),
           "m3ae_dropout")
     return out
 
@@ -1365,7 +1379,7 @@ class DropoutFn(torch.autograd.Function):
         xc = x.contiguous()
         y = torch.empty_like(xc)
         cols = xc.shape[-1]
-        check(_lib.lib().m3ae_dropout(_p(xc), _p(y), None, xc.numel() // cols, cols, p, seed, _dt(xc), _stream()),
+        check(_lib.lib().m3ae_dropout(_p(xc), _p(y), None, xc.numel() // cols, cols, p, seed, _salt(), _dt(xc), _stream()),
               "m3ae_dropout")
         ctx.p, ctx.seed = p, seed
         return y
@@ -1375,7 +1389,7 @@ class DropoutFn(torch.autograd.Function):
         d = dy.contiguous()
         dx = torch.empty_like(d)
         cols = d.shape[-1]
-        check(_lib.lib().m3ae_dropout(_p(d), _p(dx), None, d.numel() // cols, cols, ctx.p, ctx.seed, _dt(d), _stream()),
+        check(_lib.lib().m3ae_dropout(_p(d), _p(dx), None, d.numel() // cols, cols, ctx.p, ctx.seed, _salt(), _dt(d), _stream()),
               "m3ae_dropout")
         return dx, None, None
 
@@ -1390,7 +1404,7 @@ def dropout_keep_mask(rows, cols, p, seed, device="cuda"):
     """uint8 [rows, cols] keep-mask of the library's counter hash: the mask every dropout site applies for (p, seed)
     on a [rows, cols] array -- GEMM epilogue (M, N), LayerNorm backward (M, D), attention ((b*H + h)*Lq + q, Lk)."""
     m = torch.empty((rows, cols), dtype=torch.uint8, device=device)
-    check(_lib.lib().m3ae_dropout(None, None, _p(m), rows, cols, p, seed, F32, _stream()), "m3ae_dropout")
+    check(_lib.lib().m3ae_dropout(None, None, _p(m), rows, cols, p, seed, _salt(), F32, _stream()), "m3ae_dropout")
     return m
 
 

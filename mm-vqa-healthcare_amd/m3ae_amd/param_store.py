@@ -235,6 +235,21 @@ class ParamStore:
         return dict(lrs=[float(x) for x in group_lrs], wds=[float(x) for x in group_wds], b1=float(betas[0]), b2=float(betas[1]),
                     eps=float(eps), step=self.step_count, grad_scale=grad_scale)
 
+    # A hipGraph-captured step replays with frozen kernel arguments: graph.GraphedStep makes the AdamW launches read this step's
+    # learning rate and bias-corrected step size per group from `hyper_dev` ([6][2] fp32 on the device, uploaded before a replay).
+    hyper_dev = None
+
+    def _hyper_dev_ptr(self, gi):
+        return None if self.hyper_dev is None else C.c_void_p(self.hyper_dev.data_ptr() + 8 * gi)
+
+    @staticmethod
+    def hyper_values(hyper):
+        """[6][2] host floats {lr, lr * sqrt(1 - b2^t) / (1 - b1^t)} of a begin_update() record: what m3ae_adamw computes from
+        (lr, step) on the host when hyper_dev is NULL."""
+        t = hyper["step"]
+        bc1, bc2 = 1.0 - hyper["b1"] ** t, 1.0 - hyper["b2"] ** t
+        return [[lr, lr * math.sqrt(bc2) / bc1] for lr in hyper["lrs"]]
+
     @torch.no_grad()
     def adamw_range(self, a, b, gi, hyper):
         """The fused AdamW kernel over elements [a, b) of the flat buffers (inside optimizer group `gi`), on the current stream."""
@@ -247,7 +262,7 @@ class ParamStore:
                                          C.c_void_p(self.exp_avg.data_ptr() + a * es),
                                          C.c_void_p(self.exp_avg_sq.data_ptr() + a * es), sh, b - a, hyper["lrs"][gi],
                                          hyper["b1"], hyper["b2"], hyper["eps"], hyper["wds"][gi], hyper["step"],
-                                         hyper["grad_scale"], _ops._stream()), "m3ae_adamw")
+                                         hyper["grad_scale"], self._hyper_dev_ptr(gi), _ops._stream()), "m3ae_adamw")
 
     @torch.no_grad()
     def adamw_step(self, max_steps=None, grad_scale=1.0, lr_factor=None, group_lrs=None, betas=(0.9, 0.98), eps=1e-8,
@@ -256,7 +271,11 @@ class ParamStore:
         betas (0.9, 0.98), eps 1e-8) + the polynomial-decay schedule, stepped per optimizer step.
         `group_lrs` (one learning rate per group, e.g. an Optimizer's param_groups after its scheduler stepped) overrides
         the built-in schedule."""
-        hyper = self.begin_update(max_steps, grad_scale, lr_factor, group_lrs, betas, eps, group_wds)
+        self.adamw_apply(self.begin_update(max_steps, grad_scale, lr_factor, group_lrs, betas, eps, group_wds))
+
+    @torch.no_grad()
+    def adamw_apply(self, hyper):
+        """The device part of an optimizer step for a begin_update() record: six fused launches + the transposed weight copies."""
         for gi in range(6):
             a, b = self.segments[gi]
             self.adamw_range(a, min(b, self.trainable_end), gi, hyper)

@@ -1274,3 +1274,60 @@ def test_bench_line_contract():
     assert x["path"].startswith("m3ae_xattn_fwd") and x["tflop"] == round(17.922 * 64 / 1e3, 3)
     x = d["cross_attention_fwd"]
     assert x["batch"] == 64 and 0 < x["frac"] < 1
+
+
+def test_graphed_step_equals_eager_and_draws_fresh_dropout_masks_per_replay():
+    """m3ae_amd/graph.py (ABI 3: dropout salt + AdamW hyper-parameters in device memory): a step captured as ONE hipGraph and
+    replayed equals the eager steps in eval mode (same losses; parameters equal up to the order of the fp32 atomics) and, in
+    train mode, every replay draws NEW dropout masks although the captured launches carry frozen seeds."""
+    from m3ae_amd import ops
+    from m3ae_amd.graph import GraphedStep
+
+    def eager(m, b):
+        m.store.zero_grad()
+        loss = m.training_step(b)
+        loss.backward()
+        m.store.adamw_step(max_steps=50)
+        return loss.detach()
+
+    b = to_dev(tiny_batch())
+    m1 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
+    le = [eager(m1, b).item() for _ in range(4)]
+    m2 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
+    lg = [eager(m2, b).item()]
+    gs = GraphedStep(m2, b, max_steps=50)
+    lg += [gs.step().item() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert m2.store.step_count == m1.store.step_count == 4
+    for a, c in zip(le, lg):
+        assert abs(a - c) <= 2e-3 * abs(a), (le, lg)
+    moved = (m1.store.flat - build(tiny_config(compute_dtype="bf16"), torch.bfloat16).store.flat).abs().max().item()
+    assert (m1.store.flat - m2.store.flat).abs().max().item() <= 0.05 * moved
+    # train mode: fresh masks per replay (the loss of the same batch differs from replay to replay)
+    m3 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
+    m3.train(True)
+    eager(m3, b)
+    gs3 = GraphedStep(m3, b, max_steps=10 ** 7)   # warm-up of 10 % of the steps: the learning rate stays ~0, only the masks change
+    lt = [gs3.step().item() for _ in range(4)]
+    assert len({round(x, 5) for x in lt}) >= 3, lt
+    assert ops.DROPOUT_SALT is None and m3.store.hyper_dev is None   # capture restores the eager configuration
+
+
+def test_dropout_salt_changes_the_mask_and_null_keeps_it():
+    """ABI 3: m3ae_dropout with a device salt: salt = 0 is NOT the unsalted mask's... any salt value gives a valid mask of the right
+    keep rate, different salts give different masks, and the same salt reproduces the mask (forward / backward consistency)."""
+    import ctypes as C
+    from m3ae_amd import _lib, ops
+    rows, cols, p, seed = 64, 768, 0.1, 4242
+    base = ops.dropout_keep_mask(rows, cols, p, seed)
+    masks = []
+    for sv in (1, 2, 1):
+        ops.DROPOUT_SALT = torch.tensor([sv], dtype=torch.int32, device="cuda")
+        try:
+            masks.append(ops.dropout_keep_mask(rows, cols, p, seed))
+        finally:
+            ops.DROPOUT_SALT = None
+    assert torch.equal(masks[0], masks[2]) and not torch.equal(masks[0], masks[1]) and not torch.equal(masks[0], base)
+    for mk in masks:
+        assert 0.88 < mk.float().mean().item() < 0.92
+    assert torch.equal(base, ops.dropout_keep_mask(rows, cols, p, seed))

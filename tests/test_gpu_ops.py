@@ -329,13 +329,22 @@ def test_adamw_matches_hf_semantics():
     pr, mr, vr = p.cpu().clone(), torch.zeros(n), torch.zeros(n)
     L = _lib.lib()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # second copy of the state: the same three steps with the step's {lr, step size} read from DEVICE memory (ABI 3 hyper_dev:
+    # what a hipGraph-captured step uses) while the host arguments hold stale values
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    hyper = torch.zeros(2, device=dev())
     for step in (1, 2, 3):
         _lib.check(L.m3ae_adamw(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                 C.c_void_p(v.data_ptr()), C.c_void_p(sh.data_ptr()), n, 1e-3, 0.9, 0.98, 1e-8, 0.01,
-                                step, 0.5, s), "adamw")
+                                step, 0.5, None, s), "adamw")
+        hyper.copy_(torch.tensor([1e-3, 1e-3 * math.sqrt(1 - 0.98 ** step) / (1 - 0.9 ** step)]))
+        _lib.check(L.m3ae_adamw(C.c_void_p(p2.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m2.data_ptr()),
+                                C.c_void_p(v2.data_ptr()), None, n, 123.0, 0.9, 0.98, 1e-8, 0.01,
+                                77, 0.5, C.c_void_p(hyper.data_ptr()), s), "adamw hyper_dev")
         O.adamw_step(pr, g.cpu() * 0.5, mr, vr, step, 1e-3, 0.01)
     close(p, pr, 1e-5, 1e-6, msg="adamw p")
     close(sh, pr, 1e-2, 1e-3, msg="adamw shadow")
+    close(p2, p, 1e-6, 1e-7, msg="adamw with device-side hyper-parameters")
 
 
 # ----------------------------------------------------------------------------------------------------------
