@@ -95,7 +95,9 @@ enum { M3AE_GEMM_NO_PERSISTENT = 1 };
  * per call to compare them bit for bit, tools time them against each other.  The library keeps no tuning state.
  *   NT variant v: 0 = 128x128 tile, 4 = 256x256 2-stage, 7 = 256x256 ping-pong, 8 = its persistent form;
  *   TN (wgrad) variant v: 0 / 2 = 128x128 tile with 64- / 32-row steps, 5 = 256x256 ping-pong;
- *   column-tile group width g (1..12) of the ping-pong kernels' tile order. */
+ *   column-tile group width g (1..12) of the ping-pong kernels' tile order;
+ *   bits 20-21: cache policy of the NT epilogue's streams (1 plain, 2 output stores nt, 3 + residual / aux loads nt; 0 = by size).
+ *   NT variants 9 / 10 (round 4): the second-generation ping-pong kernel, one workgroup per tile / persistent. */
 #define M3AE_GEMM_NT_VARIANT(v) ((((v) + 1) & 0xf) << 8)
 #define M3AE_GEMM_TN_VARIANT(v) ((((v) + 1) & 0xf) << 12)
 #define M3AE_GEMM_COL_GROUP(g) (((g) & 0xf) << 16)

@@ -708,6 +708,12 @@ static int launch_nt(const m3ae_gemm_desc& d, hipStream_t s) {
     a.drop = make_drop(d.dropout_p, d.dropout_seed, d.dropout_salt);
     a.no_persist = (d.launch_flags & M3AE_GEMM_NO_PERSISTENT) ? 1 : 0;
     a.nt_variant = ((d.launch_flags >> 8) & 0xf) - 1;
+    a.st_policy = (d.launch_flags >> 20) & 0x3;
+    // by shape: outputs of 32 MB and more (the image-side GEMMs: 113-900 MB at per-GPU batch 256) are written -- and their residual /
+    // derivative operands read -- with the streaming policy: with the default one they evict the weight panel and the activation rows
+    // the XCD's other tiles are about to read (-5.2 % over the step's shapes, profiles/r04_nt_store_cache_policy_ab.log); small
+    // outputs (the text stream) keep the default: the next kernel finds them in L2 / Infinity Cache
+    if (a.st_policy == 0) a.st_policy = (d.M * d.N >= (int64_t)16 << 20) ? 3 : 1;
     const bool has_act = d.act != M3AE_ACT_NONE, has_dact = d.dact_aux != nullptr;
     if (!has_act && !has_dact && !d.preact) return launch_nt_v<EPI_PLAIN>(a, s);
     if (!has_dact && d.act == M3AE_ACT_RELU) return launch_nt_v<EPI_RELU>(a, s);                       // dropout allowed

@@ -34,6 +34,8 @@ struct MfmaArgs {
     int col_group;      // ping-pong NT kernels: column tiles per group of the tile order (nt_tile_coords)
     int no_persist;     // desc.launch_flags & M3AE_GEMM_NO_PERSISTENT
     int nt_variant;     // desc.launch_flags selector (-1: by shape)
+    int st_policy;      // cache policy of the epilogue's streams: 1 plain; 2 output stores nt; 3 stores nt + residual / aux loads nt
+                        // (launch_nt resolves the desc.launch_flags selector 0 = by shape)
 };
 
 // Tile order inside the (XCD-contiguous) id range: column tiles in groups of GC, row-major inside a group.  An XCD then
@@ -125,6 +127,7 @@ template <> struct Vec8<float> {
     static DEVINL void unpack(const u32x4&, float*) {}  // fp32 C tiles are never prefetched
     static DEVINL void ld(const float* p, float* x) { Vec4<float>::ld(p, x); Vec4<float>::ld(p + 4, x + 4); }
     static DEVINL void st(float* p, const float* x) { Vec4<float>::st(p, x); Vec4<float>::st(p + 4, x + 4); }
+    static DEVINL void st_policy(float* p, const float* x, int) { st(p, x); }
 };
 template <> struct Vec8<bf16_t> {
     static DEVINL void unpack(const u32x4& v, float* x) {
@@ -134,6 +137,18 @@ template <> struct Vec8<bf16_t> {
     static DEVINL void ld(const bf16_t* p, float* x) { unpack(*(const u32x4*)p, x); }
     static DEVINL void st(bf16_t* p, const float* x) {
         *(u32x4*)p = (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+    }
+    // Output stores with a cache policy (wave-uniform).  >= 2: nt (streaming: the line is the first to leave the XCD's L2).  The
+    // output of a large GEMM (113-900 MB at the step's shapes) is never re-read by the kernel itself, but written with the default
+    // policy it evicts the weight panel and the activation rows the XCD's other tiles are about to read: -11 % on 147712 x 2304
+    // x 768, -4.5 % over the step's eleven shape / epilogue classes, -5.2 % with the residual / derivative operand loaded nt as
+    // well (profiles/r04_nt_store_cache_policy_ab.log; sc1 = write-through stores measured the same as plain ones).
+    static DEVINL void st_policy(bf16_t* p, const float* x, int policy) {
+        const u32x4 v = (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+        // inline asm: hipcc sinks the two arms' stores of a __builtin_nontemporal_store / plain pair into ONE plain store (the
+        // nontemporal flag is dropped when the instructions are merged); "s_nop 1": the data registers stay valid until read
+        if (policy >= 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        else *(u32x4*)p = v;
     }
 };
 
@@ -162,10 +177,10 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
 #pragma unroll
             for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(dd[t]));
 #else
-            Vec8<TC>::st((TC*)a.preact + off, dd);
+            Vec8<TC>::st_policy((TC*)a.preact + off, dd, a.st_policy);
 #endif
         } else {
-            if (a.preact) Vec8<TC>::st((TC*)a.preact + off, x);
+            if (a.preact) Vec8<TC>::st_policy((TC*)a.preact + off, x, a.st_policy);
             act_fwd_fast_n<8>(x, act);
         }
     }
@@ -202,7 +217,7 @@ DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const f
 #pragma unroll
     for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(x[t]));
 #else
-    Vec8<TC>::st((TC*)a.C + off, x);
+    Vec8<TC>::st_policy((TC*)a.C + off, x, a.st_policy);
 #endif
 }
 

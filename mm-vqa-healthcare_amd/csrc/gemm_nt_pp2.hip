@@ -62,6 +62,7 @@ DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t
     if (a.bias && ncol < a.N) Vec8<float>::ld(a.bias + ncol, L.bias8);
     const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
     L.has_pre = BF && src != nullptr;
+    const bool nt_loads = a.st_policy >= 3;   // the residual / derivative operand is read once: streaming policy
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -72,7 +73,15 @@ DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int64_t m = m_base + 16 * i + p * 8 + (lane >> 3);
-                if (m < a.M && ncol < a.N) L.pre[i][p] = *(const u32x4*)(src + m * a.ldc + ncol);
+                if (m < a.M && ncol < a.N) {
+                    if (nt_loads) {   // (the empty asm statements keep hipcc from merging the two arms into one plain load)
+                        asm volatile("" ::: "memory");
+                        L.pre[i][p] = __builtin_nontemporal_load((const u32x4*)(src + m * a.ldc + ncol));
+                        asm volatile("" ::: "memory");
+                    } else {
+                        L.pre[i][p] = *(const u32x4*)(src + m * a.ldc + ncol);
+                    }
+                }
             }
     }
 }

@@ -28,9 +28,12 @@ NT_NO_PERSISTENT = os.environ.get("M3AE_NT_NO_PERSISTENT", "0") == "1"   # (set 
 GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = int(os.environ.get("M3AE_GEMM_NT_VARIANT", -1)), -1, 0   # (env: A/B runs of tools)
 
 
+GEMM_ST_POLICY = int(os.environ.get("M3AE_GEMM_ST_POLICY", 0))   # output-store cache policy selector (0: the kernel's default)
+
+
 def _gemm_flags():
     return ((1 if NT_NO_PERSISTENT else 0) | (((GEMM_NT_VARIANT + 1) & 0xF) << 8) | (((GEMM_TN_VARIANT + 1) & 0xF) << 12)
-            | ((GEMM_COL_GROUP & 0xF) << 16))
+            | ((GEMM_COL_GROUP & 0xF) << 16) | ((GEMM_ST_POLICY & 0x3) << 20))
 PROFILE = None  # when a list: every GEMM / attention launch is bracketed by HIP events on the launch stream
 
 

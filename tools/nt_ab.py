@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "mm-vqa-healthcare_amd"))
 import torch  # noqa: E402
 from m3ae_amd import ops  # noqa: E402
 
-VARS = tuple(int(v) for v in os.environ.get("VARS", "8,10,11").split(","))
+VARS = tuple(int(v) for v in os.environ.get("VARS", "8,10,11").split(","))   # v + 100 * p: variant v with output-store policy p (1 plain, 2 nt, 3 sc1)
 ROUNDS = int(os.environ.get("ROUNDS", 5))
 ITERS = int(os.environ.get("ITERS", 10))
 SHAPES = os.environ.get("SHAPES", "")
@@ -69,7 +69,7 @@ def main():
         ref, ref_pre = y.clone(), pre.clone()
         ident = {}
         for v in VARS:
-            ops.GEMM_NT_VARIANT = v
+            ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = v % 100, v // 100
             y.fill_(float("nan")); pre.fill_(float("nan"))
             fn()
             torch.cuda.synchronize()
@@ -80,7 +80,7 @@ def main():
         res = {v: [] for v in VARS}
         for r in range(ROUNDS):
             for v in VARS:
-                ops.GEMM_NT_VARIANT = v
+                ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = v % 100, v // 100
                 res[v].append(time_it(fn))
         line = []
         for v in VARS:
@@ -89,7 +89,7 @@ def main():
             line.append(f"v{v}: {mn * 1e3:7.1f} / {md * 1e3:7.1f} us {2.0 * m * n * k / md / 1e9:6.0f} TF/s {'==' if ident[v] else 'DIFF'}")
         print(f"  {n:5d}x{k:5d} {kind:14s} " + " | ".join(line), flush=True)
         del x, w, y, aux, pre
-    ops.GEMM_NT_VARIANT = -1
+    ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = -1, 0
     print(f"[{tag}] sum of medians: " + "  ".join(f"v{v}: {tot[v] * 1e3:8.1f} us" for v in VARS), flush=True)
 
 
