@@ -152,6 +152,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
         vb0 = (unsigned)(r0 < mb ? r0 : mb) * (unsigned)a.ldb * 2u + c0;
         vb1 = (unsigned)(r1 < mb ? r1 : mb) * (unsigned)a.ldb * 2u + c1;
     };
+    // (nt on these loads was measured too: -30 % -- the tiles of an XCD share both operands through its L2,
+    // profiles/r04_nt_dma_nt_policy_measured.log)
     auto issue_b = [&](int c) {
         const unsigned dst = lds_wave + (unsigned)(c & 3) * SLOT + A_BYTES;
         glds16_asm(bbase + (int64_t)c * CK, vb0, dst);

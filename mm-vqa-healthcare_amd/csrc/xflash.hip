@@ -23,6 +23,10 @@
 #include "xattn_common.h"
 #include <type_traits>
 
+#ifndef XF_ST_AUX
+#define XF_ST_AUX 2   // cache policy of the output rows (aux bits of buffer_store): 2 = nt, streaming (-0.8 % on the call, profiles/r04_xflash_nt_store.log)
+#endif
+
 namespace {
 
 constexpr int XF_LDS = 160 * 1024;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
                     x[2 * q + 1] += __uint_as_float(rr[q] & 0xffff0000u);
                 }
                 const u32x4 packed = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
-                __builtin_amdgcn_raw_buffer_store_b128(packed, s_rsrc, ep_voff, pass * 512 + step * row8_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(packed, s_rsrc, ep_voff, pass * 512 + step * row8_bytes, XF_ST_AUX);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -9,7 +9,9 @@ What has to live in device memory for a replay to be a NEW step (kernel argument
     the mask key (include/m3ae_hip.h, ABI 3), so every replay draws fresh masks at every site;
   * AdamW: learning rate and bias-corrected step size per optimizer group come from `ParamStore.hyper_dev` (uploaded per replay:
     the host still evaluates the reference's schedule, m3ae_utils.py:212-240, exactly as the eager step does);
-  * the batch: the caller's batch tensors are the graph's static inputs (copy new data INTO them between replays).
+  * the batch: the caller's batch tensors are the graph's static inputs (copy new data INTO them between replays); everything
+    the step reads must already be a device tensor -- e.g. `batch["vqa_targets"]` (objectives.build_vqa_targets): a host-built
+    tensor uploaded inside the captured region would be read from a stale host address at every replay.
 
 The model's second HIP stream (modules/m3ae_module.py::_fusion_two_streams) forks from and joins the capturing stream through
 events, so the graph keeps the text half and the image half as parallel branches.  Data-parallel runs (bucketed all-reduce from
@@ -50,6 +52,8 @@ class GraphedStep:
     def capture(self):
         """Capture the step.  Call after at least one eager step (lazy buffers, kernel attributes and the optimizer state exist)."""
         st = self.store
+        if "vqa_labels" in self.batch and "vqa_targets" not in self.batch:
+            raise ValueError('a graphed step needs batch["vqa_targets"] on the device (objectives.build_vqa_targets)')
         if st.exp_avg is None:
             raise RuntimeError("run one eager step before capturing (the optimizer state is allocated lazily)")
         hyper = st.begin_update(self.max_steps, self.grad_scale)   # this first graphed step is a real step

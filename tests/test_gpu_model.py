@@ -1290,7 +1290,10 @@ def test_graphed_step_equals_eager_and_draws_fresh_dropout_masks_per_replay():
         m.store.adamw_step(max_steps=50)
         return loss.detach()
 
+    from m3ae_amd.modules.objectives import build_vqa_targets
     b = to_dev(tiny_batch())
+    # a captured step must not build tensors on the host: the targets are a static device input of the graph, like the batch
+    b["vqa_targets"] = build_vqa_targets(b, tiny_config()["vqa_label_size"], "cuda")
     m1 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
     le = [eager(m1, b).item() for _ in range(4)]
     m2 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
