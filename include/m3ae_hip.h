@@ -137,7 +137,9 @@ typedef struct {
     float dropout_p;
     uint64_t dropout_seed;
     const void* dropout_salt; /* as m3ae_gemm_desc.dropout_salt */
+    int32_t launch_flags;     /* M3AE_ATTN_LEGACY_KERNELS: the round-3 bf16 kernels (tests compare the two generations); ABI 3 */
 } m3ae_attn_desc;
+enum { M3AE_ATTN_LEGACY_KERNELS = 1 };
 int64_t m3ae_attn_workspace_bytes(const m3ae_attn_desc* d, int backward);
 int m3ae_attn_fwd(const m3ae_attn_desc* d, void* stream);
 int m3ae_attn_bwd(const m3ae_attn_desc* d, void* stream);

@@ -16,6 +16,7 @@
 //   materialised in a caller workspace, row softmax, PV, through the generic GEMM kernel.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 int m3ae_gemm_generic(const m3ae_gemm_desc& d, hipStream_t s);
 
@@ -326,9 +327,9 @@ __global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP
         const char* kimg = lds + (kt & 1) * BUF;
         const char* vimg = kimg + RIMG;
         if (active) {
-            s16x8 kf[4];
+            s16x8 kf[4], vf[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[ks] = get_row_frag(kimg, r, ks, h);
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = get_row_frag(kimg, r, ks, h); vf[ks] = get_row_frag(vimg, r, ks, h); }
             f32x16 s[NQ];
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
@@ -418,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             a.delta[(b * a.H + head) * a.lse_stride + qi] = qi < a.Lq ? dlt : 0.f;
     }
 
+    const float s_init = -lse / a.scale_log2;                              // accumulator start of S': exp2(c S') = exp2(c S - lse)
+    const float keep_p = DROP ? 1.0f / a.drop.inv_keep : 1.0f;             // 1 - p
+    const float dp_init = -dlt * keep_p, dl_drop = -dlt * keep_p;          // (dropped element: dl_drop * inv_keep = -delta)
     const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
     const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
     const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
@@ -432,7 +436,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
     put_row_img(lds, kreg, t);
     put_tr_img(lds + RIMG, kreg, t);
     put_row_img(lds + RIMG + TILE_LDS, vreg, t);
-    if (nkt > 1) {
+    // global prefetch distance: two tiles.  (Round 4 measured ONE tile at three waves per SIMD -- 168 registers with one prefetch set
+    // less and 4-8 spilled registers: dQ 583 -> 730-745 us, profiles/r04_attn_bwd_experiments.log; PF2 = false is that form.)
+    constexpr bool PF2 = true;
+    if (PF2 && nkt > 1) {
         kreg = coop_load(kbase, a.k_sl, 32, a.Lk, t);
         vreg = coop_load(vbase, a.v_sl, 32, a.Lk, t);
     }
@@ -440,9 +447,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const bool last = kt + 1 == nkt;
         s16x8 kreg2 = kreg, vreg2 = vreg;
-        if (kt + 2 < nkt) {
-            kreg2 = coop_load(kbase, a.k_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
-            vreg2 = coop_load(vbase, a.v_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
+        if (PF2) {
+            if (kt + 2 < nkt) {
+                kreg2 = coop_load(kbase, a.k_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
+                vreg2 = coop_load(vbase, a.v_sl, (int64_t)(kt + 2) * 32, a.Lk, t);
+            }
+        } else if (!last) {   // tile kt + 1: requested here, written to LDS behind this tile's MFMAs
+            kreg = coop_load(kbase, a.k_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
+            vreg = coop_load(vbase, a.v_sl, (int64_t)(kt + 1) * 32, a.Lk, t);
         }
         const char* kimg = lds + (kt & 1) * BUF;
         const char* ktr = kimg + RIMG;
@@ -451,36 +463,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             s16x8 kf[4], vf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { kf[ks] = get_row_frag(kimg, r, ks, h); vf[ks] = get_row_frag(vimg, r, ks, h); }
-            f32x16 s = zero16(), dp = zero16();
+            // Row constants as the initial accumulators (round 4): S' = S - lse / c and dP' = dP - delta leave the MFMA chains, so
+            // p = exp2(c S') and dS = p dP' cost a multiply, an exponential and a multiply per element -- the subtractions, the
+            // bounds select (last key tile only) and the scale FMA of the round-3 loop are gone (the loop was VALU-bound: 16
+            // elements per lane and tile against 12 MFMAs).  Under dropout dP' = dP - delta (1 - p), so that keep: dP' / (1 - p) =
+            // dP / (1 - p) - delta, dropped: -delta = dl_drop.
+            f32x16 s, dp;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S^T[key][q]
+            for (int reg = 0; reg < 16; ++reg) { s[reg] = s_init; dp[reg] = dp_init; }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP^T[key][q] = V . dO^T
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S'^T[key][q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP'^T[key][q] = V . dO^T - delta
             uint32_t dh4[4] = {0u, 0u, 0u, 0u};
             if (DROP) {  // registers 4 r4 .. 4 r4 + 3 hold 4 consecutive keys: one hash per group
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) dh4[r4] = drop_hash(a.drop, (drow + (uint64_t)(kt * 32 + 8 * r4 + 4 * h)) >> 2);
             }
+            auto elements = [&](auto last_c) {   // the bounds select only exists in the instantiation of the last key tile
+                constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t key = (int64_t)kt * 32 + crow(reg, h);
-                float x = s[reg] * a.scale_log2;
-                bool valid = true;
-                if (MASK || BIAS || last) {
-                    const int64_t kc = key < a.Lk ? key : a.Lk - 1;
-                    if (MASK) x = fmaf(mrow[kc], LOG2E, x);
-                    if (BIAS) x = fmaf(brow[kc], LOG2E, x);
-                    valid = key < a.Lk;
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t key = (int64_t)kt * 32 + crow(reg, h);
+                    float x = s[reg] * a.scale_log2;
+                    bool valid = true;
+                    if (MASK || BIAS || LAST) {
+                        const int64_t kc = (LAST && key >= a.Lk) ? a.Lk - 1 : key;
+                        if (MASK) x = fmaf(mrow[kc], LOG2E, x);
+                        if (BIAS) x = fmaf(brow[kc], LOG2E, x);
+                        if (LAST) valid = key < a.Lk;
+                    }
+                    if (CAUSAL) valid = valid && key <= qi;
+                    float p = fast_exp2(x);
+                    if (CAUSAL || LAST) p = valid ? p : 0.f;
+                    float t = dp[reg];
+                    if (DROP) t = (rotr32(dh4[reg >> 2], 8u * (reg & 3)) >= a.drop.thr ? t : dl_drop) * a.drop.inv_keep;
+                    const float ds = p * t;
+                    if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
+                    s[reg] = ds;
                 }
-                if (CAUSAL) valid = valid && key <= qi;
-                const float p = valid ? fast_exp2(x - lse) : 0.f;
-                float dpe = dp[reg];
-                if (DROP)  // dP wrt the un-dropped P
-                    dpe = rotr32(dh4[reg >> 2], 8u * (reg & 3)) >= a.drop.thr ? dpe * a.drop.inv_keep : 0.f;
-                const float ds = p * (dpe - dlt);
-                if (BIAS) { if (dbrow && valid && qi < a.Lq) atomicAdd(dbrow + key, ds); }
-                s[reg] = ds;
-            }
+            };
+            if (last) elements(std::true_type{}); else elements(std::false_type{});
             const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
             // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
             g0 = mfma32(tr_frag(ktr, 0, 0, lane), d0, g0);
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_coop_kernel(AttnArgs a) {
             put_tr_img(nb + RIMG, kreg, t);
             put_row_img(nb + RIMG + TILE_LDS, vreg, t);
         }
-        kreg = kreg2; vreg = vreg2;
+        if (PF2) { kreg = kreg2; vreg = vreg2; }
         coop_barrier();
     }
     if (active && qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
@@ -539,7 +562,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     s16x8 doreg = coop_load(dobase, a.o_sl, 0, a.Lq, t);
     // threads 0..7: lse[4 t .. 4 t + 3], threads 8..15: delta[...] of the tile (rows padded to lse_stride % 32 == 0)
     const float* ldsrc = (t < 8 ? lrow : drow) + 4 * (t & 7);
-    f32x4 ldreg = t < 16 ? *(const f32x4*)ldsrc : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the table is staged as the accumulator start values: -lse / c (threads 0..7) and -delta (1 - p) (threads 8..15)
+    const float ldmul = t < 8 ? -1.0f / a.scale_log2 : (DROP ? -1.0f / a.drop.inv_keep : -1.0f);
+    f32x4 ldreg = t < 16 ? *(const f32x4*)ldsrc * ldmul : (f32x4){0.f, 0.f, 0.f, 0.f};
     put_row_img(lds, qreg, t);
     put_tr_img(lds + RIMG, qreg, t);
     put_row_img(lds + RIMG + TILE_LDS, doreg, t);
@@ -548,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
     if (nqt > 1) {
         qreg = coop_load(qbase, a.q_sl, 32, a.Lq, t);
         doreg = coop_load(dobase, a.o_sl, 32, a.Lq, t);
-        if (t < 16) ldreg = *(const f32x4*)(ldsrc + 32);
+        if (t < 16) ldreg = *(const f32x4*)(ldsrc + 32) * ldmul;
     }
     coop_barrier();
     for (int qt = 0; qt < nqt; ++qt) {
@@ -558,34 +583,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
         if (qt + 2 < nqt) {
             qreg2 = coop_load(qbase, a.q_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
             doreg2 = coop_load(dobase, a.o_sl, (int64_t)(qt + 2) * 32, a.Lq, t);
-            if (t < 16) ldreg2 = *(const f32x4*)(ldsrc + (int64_t)(qt + 2) * 32);
+            if (t < 16) ldreg2 = *(const f32x4*)(ldsrc + (int64_t)(qt + 2) * 32) * ldmul;
         }
         const char* qimg = lds + (qt & 1) * BUF;
         const char* qtr = qimg + RIMG;
         const char* doimg = qtr + TILE_LDS;
         const char* dotr = doimg + RIMG;
         if (active) {
-            f32x4 lse4[4], dl4[4];
+            // Row constants as the initial accumulators (round 4): the staged table holds -lse / c and -delta (1 - p) per query row
+            // (written that way by the staging threads), read straight into the accumulator tuples: S' = S - lse / c, dP' = dP -
+            // delta (1 - p); p = exp2(c S' + mask), dS = p dP' (dropout: keep dP' / (1 - p), dropped dl' / (1 - p) = -delta).
+            f32x16 s, dp;
+            f32x4 dl4[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {  // broadcast LDS reads: rows 8 g4 + 4 h .. + 3 of the tile
-                lse4[g4] = *(const f32x4*)(qimg + IMG + 4 * (8 * g4 + 4 * h));
+                const f32x4 l4 = *(const f32x4*)(qimg + IMG + 4 * (8 * g4 + 4 * h));
                 dl4[g4] = *(const f32x4*)(qimg + IMG + 128 + 4 * (8 * g4 + 4 * h));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = l4[j]; dp[4 * g4 + j] = dl4[g4][j]; }
             }
             s16x8 qfa[4], dofa[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { qfa[ks] = get_row_frag(qimg, r, ks, h); dofa[ks] = get_row_frag(doimg, r, ks, h); }
-            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S[q][key]
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S'[q][key]
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP[q][key] = dO . V^T
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP'[q][key] = dO . V^T - delta (1 - p)
             f32x16 p;
             // Dropout mask of (query row, key): hash of the GROUP (row * ld + key) >> 2 = row * (ld / 4) + (key >> 2), byte
             // key & 3.  A lane owns ONE key and 16 rows, so per lane every element has its own group -- but the four lanes
             // of a quad own the four keys of one group: each lane hashes the 4 rows (reg & 3) == (lane & 3) and the quad
             // shares them by DPP (4 hashes + 16 moves per lane and tile instead of 16 hashes with 64-bit index products:
             // the dropout instances ran 1.9x the time of the plain ones, VALU-bound).  Rows past Lq / keys past Lk carry
-            // p = 0: their mask value never matters, so no clamping.
+            // p = 0 (rows) or feed columns that are never stored (keys): their mask value never matters, so no clamping.
             uint32_t hq[4] = {0u, 0u, 0u, 0u};
             if (DROP) {
                 const uint64_t ldq = (uint64_t)(drop_ldk(a.Lk) >> 2);
@@ -595,27 +625,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
                 for (int g = 0; g < 4; ++g) hq[g] = drop_hash(a.drop, g0 + (uint64_t)(8 * g) * ldq);
             }
             const uint32_t rot = 8u * ((uint32_t)r & 3u);
+            auto elements = [&](auto last_c) {   // the row-bounds select only exists in the instantiation of the last query tile
+                constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
-                bool valid = key_ok;
-                if (last) valid = valid && qq < a.Lq;
-                if (CAUSAL) valid = valid && ki <= qq;
-                float x = fmaf(s[reg], a.scale_log2, mk);
-                if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
-                const float pv = valid ? fast_exp2(x - lse4[reg >> 2][reg & 3]) : 0.f;
-                float pd = pv, dpe = dp[reg];
-                if (DROP) {
-                    const uint32_t hv = (reg & 3) == 0 ? quad_bcast<0>(hq[reg >> 2])
-                                      : (reg & 3) == 1 ? quad_bcast<1>(hq[reg >> 2])
-                                      : (reg & 3) == 2 ? quad_bcast<2>(hq[reg >> 2]) : quad_bcast<3>(hq[reg >> 2]);
-                    const bool keep = rotr32(hv, rot) >= a.drop.thr;
-                    pd = keep ? pv * a.drop.inv_keep : 0.f;    // the P that multiplied V in the forward pass
-                    dpe = keep ? dpe * a.drop.inv_keep : 0.f;  // dP wrt the un-dropped P
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t qq = (int64_t)qt * 32 + crow(reg, h);
+                    float x = MASK ? fmaf(s[reg], a.scale_log2, mk) : s[reg] * a.scale_log2;
+                    if (BIAS) x = fmaf(bcol[(qq < a.Lq ? qq : a.Lq - 1) * a.Lk], LOG2E, x);
+                    float pv = fast_exp2(x);
+                    if (LAST || CAUSAL) {
+                        bool valid = true;
+                        if (LAST) valid = qq < a.Lq;
+                        if (CAUSAL) valid = valid && ki <= qq;
+                        pv = valid ? pv : 0.f;
+                    }
+                    if (DROP) {
+                        const uint32_t hv = (reg & 3) == 0 ? quad_bcast<0>(hq[reg >> 2])
+                                          : (reg & 3) == 1 ? quad_bcast<1>(hq[reg >> 2])
+                                          : (reg & 3) == 2 ? quad_bcast<2>(hq[reg >> 2]) : quad_bcast<3>(hq[reg >> 2]);
+                        const bool keep = rotr32(hv, rot) >= a.drop.thr;
+                        const float pik = pv * a.drop.inv_keep;
+                        p[reg] = keep ? pik : 0.f;                                   // the P that multiplied V in the forward pass
+                        s[reg] = pik * (keep ? dp[reg] : dl4[reg >> 2][reg & 3]);   // p (dP / (1 - p) - delta) | p (-delta)
+                    } else {
+                        p[reg] = pv;
+                        s[reg] = pv * dp[reg];
+                    }
                 }
-                p[reg] = pd;
-                s[reg] = pv * (dpe - dl4[reg >> 2][reg & 3]);
-            }
+            };
+            if (last) elements(std::true_type{}); else elements(std::false_type{});
             const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
             const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
             // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
@@ -644,6 +682,309 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
         store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
     }
 }
+
+// =========================================================================================================
+// Round 4: ONE LDS image per streamed operand, read by rows (ds_read_b128) AND transposed (ds_read_b64_tr_b16), and TWO streamed
+// tiles per barrier.  Counters of the round-3 kernels (profiles/r04_attn_pmc_probe.txt): waves parked at s_waitcnt / s_barrier
+// 48 % of their cycles, MFMA pipe 26 %, VALU 30 %, LDS 28 % busy -- nothing saturated, two waves per SIMD that wait; and 40 KiB of
+// ds_write_b128 per tile step and CU (five images of 4-6 KiB per workgroup: the store path moves ~79 B / clk) beside the reads.
+// Image: [32 rows][64 bf16] in 8-row x 32-column subtiles of 512 B (cdna_hip_programming.md T10 "one image for row reads AND
+// transposed reads", form (a) cut to 128-B rows): off(row, ch) = 1024 (row >> 3) + 512 (ch >> 2) + 64 (row & 7)
+// + 16 ((ch & 3) ^ ((row >> 2) & 3)), ch = 16-B chunk 0..7.  Row fragments and transposed fragments are both bank-conflict free
+// (16 lanes of a ds_read_b128 group cover 4 rows x 4 row groups = 16 different 16-B slots; the 32 lanes of a tr read cover 4
+// rows x 4 chunks x 2 halves); the staging store of a whole row by 8 lanes is 2-way (chunks c and c + 4 share a slot), 16 cycles
+// instead of 13.  4 KiB per operand tile instead of 10: the double buffer of a TWO-tile step is smaller than the old one-tile one.
+// =========================================================================================================
+DEVINL int dual_off(int row, int ch) {
+    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+DEVINL void put_dual_img(char* img, s16x8 v, int t) { *(s16x8*)(img + dual_off(t >> 3, t & 7)) = v; }
+DEVINL s16x8 dual_row_frag(const char* img, int r, int ks, int h) { return *(const s16x8*)(img + dual_off(r, 2 * ks + h)); }
+DEVINL s16x8 dual_tr_frag(const char* img, int dt, int s, int lane) {
+    const int h = lane >> 5, gg = (lane >> 4) & 1, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
+    const int row = 16 * s + 4 * h + qq, ch = 4 * dt + 2 * gg + (p >> 1), byte = 8 * (p & 1);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + dual_off(row, ch) + byte));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + dual_off(row + 8, ch) + byte));
+    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// dK / dV of the plain / key-masked / dropout instances (BERT, ViT): the math of attn_bwd_dkdv_coop_kernel on the dual images,
+// two query tiles per barrier (one global prefetch step = two tiles ahead of the tile being computed).
+template <bool MASK, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
+    if (DROP) drop_resolve(a.drop);
+    constexpr int TIMG = 4096, SUB = 2 * TIMG + 256, BUF = 2 * SUB;   // per sub-tile: Q image, dO image, 32 x (-lse / c), 32 x (-delta')
+    constexpr int UNR = DROP ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const AttnBlock blk = attn_block();
+    const int head = blk.head;
+    const int64_t b = blk.b;
+    const int64_t k0 = ((int64_t)blk.bx * 4 + wave) * 32;
+    const bool active = k0 < a.Lk;
+
+    const int64_t ki = k0 + r;
+    const int64_t krow = ki < a.Lk ? ki : a.Lk - 1;
+    const bf16_t* kp = a.k + b * a.k_sb + krow * a.k_sl + head * 64;
+    const bf16_t* vp = a.v + b * a.v_sb + krow * a.v_sl + head * 64;
+    s16x8 kfb[4], vfb[4];  // B operands: K^T[d][key], V^T[d][key]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kfb[ks] = row_frag(kp, ks, h); vfb[ks] = row_frag(vp, ks, h); }
+    const float mk = MASK ? a.key_mask[b * a.Lk + krow] * LOG2E : 0.f;
+    const bool key_ok = ki < a.Lk;
+
+    const bf16_t* qbase = a.q + b * a.q_sb + head * 64;
+    const bf16_t* dobase = a.d_o + b * a.o_sb + head * 64;
+    const float* lrow = a.lse + (b * a.H + head) * a.lse_stride;
+    const float* drow = a.delta + (b * a.H + head) * a.lse_stride;
+
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    const int nqt = (int)((a.Lq + 31) / 32);
+    const int nst = (nqt + 1) / 2;
+    // threads 0..15 stage sub-tile 0's table, 16..31 sub-tile 1's: -lse / c (first 8 of each) and -delta (1 - p) (last 8)
+    const int tsub = (t >> 4) & 1, tq = t & 15;
+    const float* ldsrc = (tq < 8 ? lrow : drow) + 4 * (tq & 7);
+    const float ldmul = tq < 8 ? -1.0f / a.scale_log2 : (DROP ? -1.0f / a.drop.inv_keep : -1.0f);
+    const int64_t ld_rows = a.lse_stride;   // a multiple of 32: the last step's second sub-tile may lie wholly past it
+    s16x8 qreg[2], doreg[2];
+    f32x4 ldreg = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int st) {   // the two tiles of step st (rows clamped; tiles past the end are never computed)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            qreg[u] = coop_load(qbase, a.q_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
+            doreg[u] = coop_load(dobase, a.o_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
+        }
+        if (t < 32) {
+            const int64_t row0 = (int64_t)(2 * st + tsub) * 32;
+            ldreg = row0 < ld_rows ? *(const f32x4*)(ldsrc + row0) * ldmul : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            put_dual_img(buf + u * SUB, qreg[u], t);
+            put_dual_img(buf + u * SUB + TIMG, doreg[u], t);
+        }
+        if (t < 32) *(f32x4*)(buf + tsub * SUB + 2 * TIMG + 16 * tq) = ldreg;
+    };
+    fetch(0);
+    stage(lds);
+    coop_barrier();
+    for (int st = 0; st < nst; ++st) {
+        const bool more = st + 1 < nst;
+        if (more) fetch(st + 1);   // lands under this step's two tiles; written to the other buffer behind them
+        const char* buf = lds + (st & 1) * BUF;
+        if (active) {
+#pragma unroll UNR   // (the dropout instances' two sub-tiles interleaved need more than 256 registers: one after the other)
+            for (int u = 0; u < 2; ++u) {
+                const int qt = 2 * st + u;
+                if (qt >= nqt) break;
+                const bool last = qt + 1 == nqt;
+                const char* qimg = buf + u * SUB;
+                const char* doimg = qimg + TIMG;
+                const char* tbl = doimg + TIMG;
+                f32x16 s, dp;
+                f32x4 dl4[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {  // broadcast LDS reads: rows 8 g4 + 4 h .. + 3 of the tile -> accumulator start values
+                    const f32x4 l4 = *(const f32x4*)(tbl + 4 * (8 * g4 + 4 * h));
+                    dl4[g4] = *(const f32x4*)(tbl + 128 + 4 * (8 * g4 + 4 * h));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = l4[j]; dp[4 * g4 + j] = dl4[g4][j]; }
+                }
+                s16x8 qfa[4], dofa[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { qfa[ks] = dual_row_frag(qimg, r, ks, h); dofa[ks] = dual_row_frag(doimg, r, ks, h); }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = mfma32(qfa[ks], kfb[ks], s);      // S'[q][key] = Q K^T - lse / c
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = mfma32(dofa[ks], vfb[ks], dp);   // dP'[q][key] = dO V^T - delta (1 - p)
+                f32x16 p;
+                uint32_t hq[4] = {0u, 0u, 0u, 0u};
+                if (DROP) {   // (the quad-shared hashes of attn_bwd_dkdv_coop_kernel)
+                    const uint64_t ldq = (uint64_t)(drop_ldk(a.Lk) >> 2);
+                    const uint64_t g0 = (uint64_t)((b * a.H + head) * a.Lq + (int64_t)qt * 32 + 4 * h + (lane & 3)) * ldq +
+                                        (uint64_t)((k0 + (r & ~3)) >> 2);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) hq[g] = drop_hash(a.drop, g0 + (uint64_t)(8 * g) * ldq);
+                }
+                const uint32_t rot = 8u * ((uint32_t)r & 3u);
+                auto elements = [&](auto last_c) {
+                    constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float x = MASK ? fmaf(s[reg], a.scale_log2, mk) : s[reg] * a.scale_log2;
+                        float pv = fast_exp2(x);
+                        if (LAST) pv = (int64_t)qt * 32 + crow(reg, h) < a.Lq ? pv : 0.f;
+                        if (DROP) {
+                            const uint32_t hv = (reg & 3) == 0 ? quad_bcast<0>(hq[reg >> 2])
+                                              : (reg & 3) == 1 ? quad_bcast<1>(hq[reg >> 2])
+                                              : (reg & 3) == 2 ? quad_bcast<2>(hq[reg >> 2]) : quad_bcast<3>(hq[reg >> 2]);
+                            const bool keep = rotr32(hv, rot) >= a.drop.thr;
+                            const float pik = pv * a.drop.inv_keep;
+                            p[reg] = keep ? pik : 0.f;
+                            s[reg] = pik * (keep ? dp[reg] : dl4[reg >> 2][reg & 3]);
+                        } else {
+                            p[reg] = pv;
+                            s[reg] = pv * dp[reg];
+                        }
+                    }
+                };
+                if (last) elements(std::true_type{}); else elements(std::false_type{});
+                const s16x8 p0 = pack_acc(p, 0), p1 = pack_acc(p, 1);
+                const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+                // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+                dv0 = mfma32(dual_tr_frag(doimg, 0, 0, lane), p0, dv0);
+                dv1 = mfma32(dual_tr_frag(doimg, 1, 0, lane), p0, dv1);
+                dv0 = mfma32(dual_tr_frag(doimg, 0, 1, lane), p1, dv0);
+                dv1 = mfma32(dual_tr_frag(doimg, 1, 1, lane), p1, dv1);
+                dk0 = mfma32(dual_tr_frag(qimg, 0, 0, lane), d0, dk0);
+                dk1 = mfma32(dual_tr_frag(qimg, 1, 0, lane), d0, dk1);
+                dk0 = mfma32(dual_tr_frag(qimg, 0, 1, lane), d1, dk0);
+                dk1 = mfma32(dual_tr_frag(qimg, 1, 1, lane), d1, dk1);
+            }
+        }
+        if (more) stage(lds + ((st + 1) & 1) * BUF);
+        coop_barrier();
+    }
+    if (active && key_ok) {
+        store_rows(a.dk + b * a.k_sb + ki * a.k_sl + head * 64, dk0, dk1, a.scale, h);
+        store_rows(a.dv + b * a.v_sb + ki * a.v_sl + head * 64, dv0, dv1, 1.0f, h);
+    }
+}
+
+// dQ (and delta) of the plain / key-masked / dropout instances: the math of attn_bwd_dq_coop_kernel on the dual images (K: row
+// fragments for S, transposed fragments for dQ; V: row fragments for dP), two key tiles per barrier.
+template <bool MASK, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
+    if (DROP) drop_resolve(a.drop);
+    constexpr int TIMG = 4096, SUB = 2 * TIMG, BUF = 2 * SUB;   // per sub-tile: K image, V image
+    constexpr int UNR = DROP ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const AttnBlock blk = attn_block();
+    const int head = blk.head;
+    const int64_t b = blk.b;
+    const int64_t q0 = ((int64_t)blk.bx * 4 + wave) * 32;
+    const bool active = q0 < a.Lq;
+
+    const int64_t qi = q0 + r;
+    const int64_t qrow = qi < a.Lq ? qi : a.Lq - 1;
+    const bf16_t* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * 64;
+    const bf16_t* dop = a.d_o + b * a.o_sb + qrow * a.o_sl + head * 64;
+    s16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(qp, ks, h); dof[ks] = row_frag(dop, ks, h); }
+    const float lse = a.lse[(b * a.H + head) * a.lse_stride + qrow];
+    float dlt = 0.f;   // delta[q] = sum_d dO[q][d] O[q][d] (published for the dK/dV kernel, as attn_bwd_dq_coop_kernel does)
+    {
+        const bf16_t* op = a.o + b * a.o_sb + qrow * a.o_sl + head * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const s16x8 of = row_frag(op, ks, h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt = fmaf(bf2f((bf16_t)of[j]), bf2f((bf16_t)dof[ks][j]), dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (h == 0 && active && qi < a.lse_stride)
+            a.delta[(b * a.H + head) * a.lse_stride + qi] = qi < a.Lq ? dlt : 0.f;
+    }
+    const float s_init = -lse / a.scale_log2;
+    const float keep_p = DROP ? 1.0f / a.drop.inv_keep : 1.0f;
+    const float dp_init = -dlt * keep_p, dl_drop = -dlt * keep_p;
+    const bf16_t* kbase = a.k + b * a.k_sb + head * 64;
+    const bf16_t* vbase = a.v + b * a.v_sb + head * 64;
+    const float* mrow = MASK ? a.key_mask + b * a.Lk : nullptr;
+
+    f32x16 g0 = zero16(), g1 = zero16();
+    const int nkt = (int)((a.Lk + 31) / 32);
+    const int nst = (nkt + 1) / 2;
+    const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi) * drop_ldk(a.Lk));
+    s16x8 kreg[2], vreg[2];
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kreg[u] = coop_load(kbase, a.k_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
+            vreg[u] = coop_load(vbase, a.v_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
+        }
+    };
+    auto stage = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            put_dual_img(buf + u * SUB, kreg[u], t);
+            put_dual_img(buf + u * SUB + TIMG, vreg[u], t);
+        }
+    };
+    fetch(0);
+    stage(lds);
+    coop_barrier();
+    for (int st = 0; st < nst; ++st) {
+        const bool more = st + 1 < nst;
+        if (more) fetch(st + 1);
+        const char* buf = lds + (st & 1) * BUF;
+        if (active) {
+#pragma unroll UNR
+            for (int u = 0; u < 2; ++u) {
+                const int kt = 2 * st + u;
+                if (kt >= nkt) break;
+                const bool last = kt + 1 == nkt;
+                const char* kimg = buf + u * SUB;
+                const char* vimg = kimg + TIMG;
+                s16x8 kf[4], vf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { kf[ks] = dual_row_frag(kimg, r, ks, h); vf[ks] = dual_row_frag(vimg, r, ks, h); }
+                f32x16 s, dp;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) { s[reg] = s_init; dp[reg] = dp_init; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = mfma32(kf[ks], qf[ks], s);      // S'^T[key][q]
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = mfma32(vf[ks], dof[ks], dp);   // dP'^T[key][q]
+                uint32_t dh4[4] = {0u, 0u, 0u, 0u};
+                if (DROP) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) dh4[r4] = drop_hash(a.drop, (drow + (uint64_t)(kt * 32 + 8 * r4 + 4 * h)) >> 2);
+                }
+                auto elements = [&](auto last_c) {
+                    constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t key = (int64_t)kt * 32 + crow(reg, h);
+                        float x = s[reg] * a.scale_log2;
+                        if (MASK) x = fmaf(mrow[(LAST && key >= a.Lk) ? a.Lk - 1 : key], LOG2E, x);
+                        float p = fast_exp2(x);
+                        if (LAST) p = key < a.Lk ? p : 0.f;
+                        float tt = dp[reg];
+                        if (DROP) tt = (rotr32(dh4[reg >> 2], 8u * (reg & 3)) >= a.drop.thr ? tt : dl_drop) * a.drop.inv_keep;
+                        s[reg] = p * tt;
+                    }
+                };
+                if (last) elements(std::true_type{}); else elements(std::false_type{});
+                const s16x8 d0 = pack_acc(s, 0), d1 = pack_acc(s, 1);
+                // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+                g0 = mfma32(dual_tr_frag(kimg, 0, 0, lane), d0, g0);
+                g1 = mfma32(dual_tr_frag(kimg, 1, 0, lane), d0, g1);
+                g0 = mfma32(dual_tr_frag(kimg, 0, 1, lane), d1, g0);
+                g1 = mfma32(dual_tr_frag(kimg, 1, 1, lane), d1, g1);
+            }
+        }
+        if (more) stage(lds + ((st + 1) & 1) * BUF);
+        coop_barrier();
+    }
+    if (active && qi < a.Lq) store_rows(a.dq + b * a.q_sb + qi * a.q_sl + head * 64, g0, g1, a.scale, h);
+}
+
+// (A forward kernel in the same mould -- K by rows, V transposed from dual images, two key tiles per barrier -- was built and measured
+// SLOWER than attn_fwd_coop_kernel: 543 vs 452 us plain, 686 vs 620 with dropout, 784 vs 571 with a key mask at 577 x 577, B = 256,
+// profiles/r04_attn_generation_check.log: the forward reads each image one way only, so the dual layout saves no staging stores
+// there, and at 32 KiB of LDS and 167 registers it loses the fourth wave per SIMD the round-3 kernel runs with.  Not kept.)
 
 // coop kernels: mask / bias / causal as below plus the dropout instances: BERT layers (optional key mask) and T5 layers
 // (relative-position bias, optionally causal)
@@ -832,8 +1173,23 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         dim3 gq((unsigned)cdiv(cdiv(d.Lq, 32), 4), (unsigned)d.H, (unsigned)d.B);
         dim3 gk((unsigned)cdiv(cdiv(d.Lk, 32), 4), (unsigned)d.H, (unsigned)d.B);
         int rc = 0;
-        ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );   // also computes (and publishes) delta = rowsum(dO * O)
-        ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
+        const bool gen4 = !a.pos_bias && !a.causal && !(d.launch_flags & M3AE_ATTN_LEGACY_KERNELS);
+        if (gen4) {   // round-4 kernels: one LDS image per operand, two tiles per barrier; also publishes delta = rowsum(dO * O)
+            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, true>), gq, dim3(256), 0, s, a);
+                              else hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, false>), gq, dim3(256), 0, s, a); }
+            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, true>), gq, dim3(256), 0, s, a);
+                   else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, false>), gq, dim3(256), 0, s, a); }
+        } else {
+            ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );   // also computes (and publishes) delta = rowsum(dO * O)
+        }
+        if (gen4) {
+            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, true>), gk, dim3(256), 0, s, a);
+                              else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, false>), gk, dim3(256), 0, s, a); }
+            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, true>), gk, dim3(256), 0, s, a);
+                   else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, false>), gk, dim3(256), 0, s, a); }
+        } else {
+            ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
+        }
         if (rc) return rc;
         return hip_launch_status();
     }

@@ -36,7 +36,7 @@ class AttnDesc(C.Structure):
         ("key_mask", vp), ("pos_bias", vp), ("scale", f32), ("causal", i32),
         ("lse", vp), ("lse_stride", i64), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
         ("d_o", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp), ("d_pos_bias", vp),
-        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("dropout_salt", vp),
+        ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("dropout_salt", vp), ("launch_flags", i32),
     ]
 
 
@@ -57,6 +57,7 @@ class XattnDesc(C.Structure):
 
 
 GEMM_NO_PERSISTENT = 1                            # m3ae_gemm_desc.launch_flags
+ATTN_LEGACY_KERNELS = 1                           # m3ae_attn_desc.launch_flags
 XATTN_NO_PERSISTENT, XATTN_LEGACY_CHAIN = 1, 2    # m3ae_xattn_desc.launch_flags
 ABI_VERSION = 3
 

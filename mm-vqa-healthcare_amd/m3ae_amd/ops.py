@@ -28,6 +28,7 @@ NT_NO_PERSISTENT = os.environ.get("M3AE_NT_NO_PERSISTENT", "0") == "1"   # (set 
 GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = int(os.environ.get("M3AE_GEMM_NT_VARIANT", -1)), -1, 0   # (env: A/B runs of tools)
 
 
+ATTN_LEGACY = os.environ.get("M3AE_ATTN_LEGACY", "0") == "1"   # round-3 attention kernels (tests / tools compare the generations)
 GEMM_ST_POLICY = int(os.environ.get("M3AE_GEMM_ST_POLICY", 0))   # output-store cache policy selector (0: the kernel's default)
 
 
@@ -484,6 +485,7 @@ def _attn_desc(B, H, Lq, Lk, Dh, q, k, v, o, key_mask, pos_bias, scale, causal, 
     d.lse = lse.data_ptr() if lse is not None else None
     d.lse_stride = lse_stride
     d.dtype = dtype
+    d.launch_flags = _lib.ATTN_LEGACY_KERNELS if ATTN_LEGACY else 0
     return d
 
 

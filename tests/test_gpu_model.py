@@ -1304,8 +1304,10 @@ def test_graphed_step_equals_eager_and_draws_fresh_dropout_masks_per_replay():
     assert m2.store.step_count == m1.store.step_count == 4
     for a, c in zip(le, lg):
         assert abs(a - c) <= 2e-3 * abs(a), (le, lg)
-    moved = (m1.store.flat - build(tiny_config(compute_dtype="bf16"), torch.bfloat16).store.flat).abs().max().item()
-    assert (m1.store.flat - m2.store.flat).abs().max().item() <= 0.05 * moved
+    # AdamW normalises every gradient element: where the gradient is rounding noise (the order of the fp32 atomics differs between
+    # two runs) an element moves by +-lr either way, so the two parameter vectors are compared in L2 against the distance moved
+    moved = (m1.store.flat - build(tiny_config(compute_dtype="bf16"), torch.bfloat16).store.flat).double().norm().item()
+    assert (m1.store.flat - m2.store.flat).double().norm().item() <= 0.1 * moved
     # train mode: fresh masks per replay (the loss of the same batch differs from replay to replay)
     m3 = build(tiny_config(compute_dtype="bf16"), torch.bfloat16)
     m3.train(True)
