@@ -698,7 +698,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
 DEVINL int dual_off(int row, int ch) {
     return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
-DEVINL void put_dual_img(char* img, s16x8 v, int t) { *(s16x8*)(img + dual_off(t >> 3, t & 7)) = v; }
+// staging map of the dual images: thread t -> row (t & 127) >> 2, chunk (t & 3) + 4 (t >> 7).  The 8 lanes of a ds_write_b128
+// group then cover 2 rows x 4 chunks = 8 different 16-B slots (a whole row by 8 lanes puts chunks c and c + 4 on one slot: 2-way,
+// SQ_LDS_BANK_CONFLICT = 13 % of the LDS cycles of the first version); the global loads become 64-B segments of 16 rows.
+DEVINL s16x8 dual_load(const bf16_t* base, int64_t sl, int64_t row0, int64_t nrows, int t) {
+    int64_t row = row0 + ((t & 127) >> 2);
+    row = row < nrows ? row : nrows - 1;
+    return *(const s16x8*)(base + row * sl + ((t & 3) + 4 * (t >> 7)) * 8);
+}
+DEVINL void put_dual_img(char* img, s16x8 v, int t) { *(s16x8*)(img + dual_off((t & 127) >> 2, (t & 3) + 4 * (t >> 7))) = v; }
 DEVINL s16x8 dual_row_frag(const char* img, int r, int ks, int h) { return *(const s16x8*)(img + dual_off(r, 2 * ks + h)); }
 DEVINL s16x8 dual_tr_frag(const char* img, int dt, int s, int lane) {
     const int h = lane >> 5, gg = (lane >> 4) & 1, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3;
@@ -755,8 +763,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     auto fetch = [&](int st) {   // the two tiles of step st (rows clamped; tiles past the end are never computed)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            qreg[u] = coop_load(qbase, a.q_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
-            doreg[u] = coop_load(dobase, a.o_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
+            qreg[u] = dual_load(qbase, a.q_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
+            doreg[u] = dual_load(dobase, a.o_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
         }
         if (t < 32) {
             const int64_t row0 = (int64_t)(2 * st + tsub) * 32;
@@ -911,8 +919,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     auto fetch = [&](int st) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            kreg[u] = coop_load(kbase, a.k_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
-            vreg[u] = coop_load(vbase, a.v_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
+            kreg[u] = dual_load(kbase, a.k_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
+            vreg[u] = dual_load(vbase, a.v_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
         }
     };
     auto stage = [&](char* buf) {
