@@ -310,6 +310,8 @@ int m3ae_transpose_bf16_batched(const void* jobs_dev, int njobs, int64_t total_t
 /* elementwise: out = cast(in) (dtype_in -> dtype_out), n elements */
 int m3ae_cast(const void* in, void* out, int64_t n, int dtype_in, int dtype_out, void* stream);
 /* out = a + b (same dtype) */
+/* stream-ordered zero fill of `bytes` bytes (the flat gradient buffer before a step; hipMemsetAsync) */
+int m3ae_zero(void* p, int64_t bytes, void* stream);
 int m3ae_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 /* dx = dy * act'(x_pre) ; y = act(x) standalone forms */
 int m3ae_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);

@@ -916,9 +916,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(MfmaArgs a) {
                 const int64_t n2 = n0 + wc * 64 + j * 16 + (lane & 15);
                 float* p = C + n1 * a.ldc + n2;
                 const float x = acc[i][j][r] * a.alpha;
+#ifdef M3AE_EXP_TN_NOATOMIC   // timing experiment: the split-K epilogue's share of the kernel
+                asm volatile("" ::"v"(x), "v"(p));
+#else
                 if (atomic) atomicAdd(p, x);
                 else if (a.accumulate) *p += x;
                 else *p = x;
+#endif
             }
 }
 

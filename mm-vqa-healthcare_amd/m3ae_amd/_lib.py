@@ -94,6 +94,7 @@ _SIGS = {
     "m3ae_cast_transpose_batched": (C.c_int, [vp, C.c_int, i64, vp]),
     "m3ae_transpose_bf16_batched": (C.c_int, [vp, C.c_int, i64, vp]),
     "m3ae_cast": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
+    "m3ae_zero": (C.c_int, [vp, i64, vp]),
     "m3ae_add": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "m3ae_act_fwd": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp]),
     "m3ae_act_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, vp]),

@@ -194,14 +194,19 @@ class M3AETransformerSS(_Base):
                                                                   self.multi_modal_vision_layers)):
             if mask_image and self.hparams.config["mim_layer"] == layer_idx:
                 ret[f"multi_modal_text_feats_{layer_idx}"], ret[f"multi_modal_image_feats_{layer_idx}"] = x, y
+            # x and y each feed both layers of the pair: forked on the stream that produced them, so the two gradients are joined
+            # there by the library's add (ops.Fork2Fn)
+            with torch.cuda.stream(side):
+                xa, xb = ops.fork2(x)
+            ya, yb = ops.fork2(y)
             side.wait_event(ev_y)
             y.record_stream(side)
             with torch.cuda.stream(side):
-                x1 = text_layer(x, y, mt, mv)
+                x1 = text_layer(xa, yb, mt, mv)
                 ev_x1 = side.record_event()
             main.wait_event(ev_x)
             x.record_stream(main)
-            y1 = image_layer(y, x, mv, mt)
+            y1 = image_layer(ya, xb, mv, mt)
             ev_y = main.record_event()
             x, y, ev_x = x1, y1, ev_x1
         main.wait_event(ev_x)
@@ -292,8 +297,9 @@ class M3AETransformerSS(_Base):
                                                                       self.multi_modal_vision_layers)):
                 if mask_image and self.hparams.config["mim_layer"] == layer_idx:
                     ret[f"multi_modal_text_feats_{layer_idx}"], ret[f"multi_modal_image_feats_{layer_idx}"] = x, y
-                x1 = text_layer(x, y, mt, mv)
-                y1 = image_layer(y, x, mv, mt)
+                (xa, xb), (ya, yb) = ops.fork2(x), ops.fork2(y)
+                x1 = text_layer(xa, yb, mt, mv)
+                y1 = image_layer(ya, xb, mv, mt)
                 x, y = x1, y1
         else:
             x, y = self._fusion_two_streams(text_tower, v, mt, mv, mask_image, ret, main, side, ev_inputs)

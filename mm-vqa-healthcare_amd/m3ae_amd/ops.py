@@ -266,6 +266,37 @@ def _grad_buf(p):
     return p.grad
 
 
+def add(a, b, out=None):
+    """out = a + b on the library's streaming add (same shape / dtype, contiguous)."""
+    _need_cuda(a)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a) if out is None else out
+    check(_lib.lib().m3ae_add(_p(a), _p(b), _p(out), a.numel(), _dt(a), _stream()), "m3ae_add")
+    return out
+
+
+class Fork2Fn(torch.autograd.Function):
+    """Identity with two outputs for a tensor that feeds two consumers (a fusion layer's x / y feed the text layer AND the image
+    layer of the pair, m3ae_module.py:269-278): the two gradients meet here and are summed by the library's add instead of by
+    autograd's accumulation (12 ATen adds per step in round 3).  Runs on the stream of its forward, i.e. the producer's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None:
+            return gb
+        if gb is None:
+            return ga
+        return add(ga, gb)
+
+
+def fork2(x):
+    return Fork2Fn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else (x, x)
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b + extra_bias) (+ residual).  nn.Linear sites of clip_model.py / bert_model.py /
     m3ae_module.py.  `weight` / `bias` are Parameters or PackedParams; `anchors` are the underlying Parameters of a

@@ -196,7 +196,8 @@ class ParamStore:
 
     # ---- optimizer -----------------------------------------------------------------------------------------
     def zero_grad(self):
-        self.grad.zero_()
+        from . import ops as _ops
+        _lib.check(_lib.lib().m3ae_zero(C.c_void_p(self.grad.data_ptr()), self.grad.numel() * 4, _ops._stream()), "m3ae_zero")
 
     def lr_factor(self, step, max_steps):
         """transformers get_polynomial_decay_schedule_with_warmup (m3ae_utils.py:232-238), lr_init-relative."""
