@@ -131,6 +131,12 @@ def main():
                          "backward hooks, one-tile-per-workgroup NT launches) -- a rehearsal of the scaling run, not a metric")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else this process (or a library in it: RCCL prints a version
+    # banner to stdout when its first communicator is created) writes to fd 1 goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -584,7 +590,8 @@ def main():
             line["config"]["workload"] = ("configs[4] towers: ViT-L/16 (23 blocks, width 1024) + RoBERTa-large + 6 co-attention "
                                           "layers (768), 512x512 (1025 image tokens), head: " + args.head +
                                           (" " + args.t5 if args.head == "t5" else ""))
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()  # rank 0 runs the roofline / cpu_baseline legs alone; the others wait here, not in teardown
         dist.destroy_process_group()
