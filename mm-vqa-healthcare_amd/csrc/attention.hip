@@ -695,6 +695,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_coop_kernel(AttnArgs a) 
 // rows x 4 chunks x 2 halves); the staging store of a whole row by 8 lanes is 2-way (chunks c and c + 4 share a slot), 16 cycles
 // instead of 13.  4 KiB per operand tile instead of 10: the double buffer of a TWO-tile step is smaller than the old one-tile one.
 // =========================================================================================================
+#ifndef TPS_PLAIN
+#define TPS_PLAIN 4   // streamed tiles per barrier of the instances without dropout: 4 (-3 % against 2, profiles/r04_attn_tiles_per_barrier.log); the dropout instances keep 2 (registers)
+#endif
 DEVINL int dual_off(int row, int ch) {
     return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
@@ -719,11 +722,11 @@ DEVINL s16x8 dual_tr_frag(const char* img, int dt, int s, int lane) {
 
 // dK / dV of the plain / key-masked / dropout instances (BERT, ViT): the math of attn_bwd_dkdv_coop_kernel on the dual images,
 // two query tiles per barrier (one global prefetch step = two tiles ahead of the tile being computed).
-template <bool MASK, bool DROP>
+template <bool MASK, bool DROP, int TPS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     if (DROP) drop_resolve(a.drop);
-    constexpr int TIMG = 4096, SUB = 2 * TIMG + 256, BUF = 2 * SUB;   // per sub-tile: Q image, dO image, 32 x (-lse / c), 32 x (-delta')
-    constexpr int UNR = DROP ? 1 : 2;
+    constexpr int TIMG = 4096, SUB = 2 * TIMG + 256, BUF = TPS * SUB;   // per sub-tile: Q image, dO image, 32 x (-lse / c), 32 x (-delta')
+    constexpr int UNR = DROP ? 1 : 2;   // sub-tiles interleaved by the compiler (registers)
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -752,32 +755,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
     const int nqt = (int)((a.Lq + 31) / 32);
-    const int nst = (nqt + 1) / 2;
+    const int nst = (nqt + TPS - 1) / TPS;
     // threads 0..15 stage sub-tile 0's table, 16..31 sub-tile 1's: -lse / c (first 8 of each) and -delta (1 - p) (last 8)
-    const int tsub = (t >> 4) & 1, tq = t & 15;
+    const int tsub = t >> 4, tq = t & 15;   // (threads 0 .. 16 TPS - 1 stage the tables)
     const float* ldsrc = (tq < 8 ? lrow : drow) + 4 * (tq & 7);
     const float ldmul = tq < 8 ? -1.0f / a.scale_log2 : (DROP ? -1.0f / a.drop.inv_keep : -1.0f);
     const int64_t ld_rows = a.lse_stride;   // a multiple of 32: the last step's second sub-tile may lie wholly past it
-    s16x8 qreg[2], doreg[2];
+    s16x8 qreg[TPS], doreg[TPS];
     f32x4 ldreg = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int st) {   // the two tiles of step st (rows clamped; tiles past the end are never computed)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            qreg[u] = dual_load(qbase, a.q_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
-            doreg[u] = dual_load(dobase, a.o_sl, (int64_t)(2 * st + u) * 32, a.Lq, t);
+        for (int u = 0; u < TPS; ++u) {
+            qreg[u] = dual_load(qbase, a.q_sl, (int64_t)(TPS * st + u) * 32, a.Lq, t);
+            doreg[u] = dual_load(dobase, a.o_sl, (int64_t)(TPS * st + u) * 32, a.Lq, t);
         }
-        if (t < 32) {
-            const int64_t row0 = (int64_t)(2 * st + tsub) * 32;
+        if (t < 16 * TPS) {
+            const int64_t row0 = (int64_t)(TPS * st + tsub) * 32;
             ldreg = row0 < ld_rows ? *(const f32x4*)(ldsrc + row0) * ldmul : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage = [&](char* buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TPS; ++u) {
             put_dual_img(buf + u * SUB, qreg[u], t);
             put_dual_img(buf + u * SUB + TIMG, doreg[u], t);
         }
-        if (t < 32) *(f32x4*)(buf + tsub * SUB + 2 * TIMG + 16 * tq) = ldreg;
+        if (t < 16 * TPS) *(f32x4*)(buf + tsub * SUB + 2 * TIMG + 16 * tq) = ldreg;
     };
     fetch(0);
     stage(lds);
@@ -788,8 +791,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         const char* buf = lds + (st & 1) * BUF;
         if (active) {
 #pragma unroll UNR   // (the dropout instances' two sub-tiles interleaved need more than 256 registers: one after the other)
-            for (int u = 0; u < 2; ++u) {
-                const int qt = 2 * st + u;
+            for (int u = 0; u < TPS; ++u) {
+                const int qt = TPS * st + u;
                 if (qt >= nqt) break;
                 const bool last = qt + 1 == nqt;
                 const char* qimg = buf + u * SUB;
@@ -867,11 +870,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 
 // dQ (and delta) of the plain / key-masked / dropout instances: the math of attn_bwd_dq_coop_kernel on the dual images (K: row
 // fragments for S, transposed fragments for dQ; V: row fragments for dP), two key tiles per barrier.
-template <bool MASK, bool DROP>
+template <bool MASK, bool DROP, int TPS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     if (DROP) drop_resolve(a.drop);
-    constexpr int TIMG = 4096, SUB = 2 * TIMG, BUF = 2 * SUB;   // per sub-tile: K image, V image
-    constexpr int UNR = DROP ? 1 : 2;
+    constexpr int TIMG = 4096, SUB = 2 * TIMG, BUF = TPS * SUB;   // per sub-tile: K image, V image
+    constexpr int UNR = DROP ? 1 : 2;   // sub-tiles interleaved by the compiler (registers)
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -913,19 +916,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
 
     f32x16 g0 = zero16(), g1 = zero16();
     const int nkt = (int)((a.Lk + 31) / 32);
-    const int nst = (nkt + 1) / 2;
+    const int nst = (nkt + TPS - 1) / TPS;
     const uint64_t drow = (uint64_t)(((b * a.H + head) * a.Lq + qi) * drop_ldk(a.Lk));
-    s16x8 kreg[2], vreg[2];
+    s16x8 kreg[TPS], vreg[TPS];
     auto fetch = [&](int st) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            kreg[u] = dual_load(kbase, a.k_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
-            vreg[u] = dual_load(vbase, a.v_sl, (int64_t)(2 * st + u) * 32, a.Lk, t);
+        for (int u = 0; u < TPS; ++u) {
+            kreg[u] = dual_load(kbase, a.k_sl, (int64_t)(TPS * st + u) * 32, a.Lk, t);
+            vreg[u] = dual_load(vbase, a.v_sl, (int64_t)(TPS * st + u) * 32, a.Lk, t);
         }
     };
     auto stage = [&](char* buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TPS; ++u) {
             put_dual_img(buf + u * SUB, kreg[u], t);
             put_dual_img(buf + u * SUB + TIMG, vreg[u], t);
         }
@@ -939,8 +942,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
         const char* buf = lds + (st & 1) * BUF;
         if (active) {
 #pragma unroll UNR
-            for (int u = 0; u < 2; ++u) {
-                const int kt = 2 * st + u;
+            for (int u = 0; u < TPS; ++u) {
+                const int kt = TPS * st + u;
                 if (kt >= nkt) break;
                 const bool last = kt + 1 == nkt;
                 const char* kimg = buf + u * SUB;
@@ -1183,18 +1186,18 @@ extern "C" int m3ae_attn_bwd(const m3ae_attn_desc* dp, void* stream) {
         int rc = 0;
         const bool gen4 = !a.pos_bias && !a.causal && !(d.launch_flags & M3AE_ATTN_LEGACY_KERNELS);
         if (gen4) {   // round-4 kernels: one LDS image per operand, two tiles per barrier; also publishes delta = rowsum(dO * O)
-            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, true>), gq, dim3(256), 0, s, a);
-                              else hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, false>), gq, dim3(256), 0, s, a); }
-            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, true>), gq, dim3(256), 0, s, a);
-                   else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, false>), gq, dim3(256), 0, s, a); }
+            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, true, 2>), gq, dim3(256), 0, s, a);
+                              else hipLaunchKernelGGL((attn_bwd_dq2_kernel<true, false, TPS_PLAIN>), gq, dim3(256), 0, s, a); }
+            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, true, 2>), gq, dim3(256), 0, s, a);
+                   else hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, false, TPS_PLAIN>), gq, dim3(256), 0, s, a); }
         } else {
             ATTN_DISPATCH_COOP(rc, attn_bwd_dq_coop_kernel, gq, s, a, );   // also computes (and publishes) delta = rowsum(dO * O)
         }
         if (gen4) {
-            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, true>), gk, dim3(256), 0, s, a);
-                              else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, false>), gk, dim3(256), 0, s, a); }
-            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, true>), gk, dim3(256), 0, s, a);
-                   else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, false>), gk, dim3(256), 0, s, a); }
+            if (a.key_mask) { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, true, 2>), gk, dim3(256), 0, s, a);
+                              else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, false, TPS_PLAIN>), gk, dim3(256), 0, s, a); }
+            else { if (a.has_drop) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, true, 2>), gk, dim3(256), 0, s, a);
+                   else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<false, false, TPS_PLAIN>), gk, dim3(256), 0, s, a); }
         } else {
             ATTN_DISPATCH_COOP(rc, attn_bwd_dkdv_coop_kernel, gk, s, a, );
         }
