@@ -21,6 +21,17 @@ DEVINL unsigned xcd_remap(unsigned bid, unsigned nwg) {
 DEVINL void glds16(const void* src, char* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_uniform, 16, 0, 0);
 }
+// The same piece from inline asm (M0 saved / restored in the statement).  hipcc tracks the BUILTIN as a pending LDS store and puts
+// `s_waitcnt vmcnt(0)` in front of every later LDS access it cannot prove disjoint -- in front of the first ds_write of an epilogue
+// (gemm_nt_pp2.hip) and, found in round 4, in front of EVERY ds_read_b64_tr_b16 fragment read of the wgrad (TN) kernels: each phase of
+// their main loops drained the whole ring (the .s of round 3 shows it), i.e. the counted-vmcnt prefetch never overlapped anything.
+// The asm form is invisible to that bookkeeping: every wait for these pieces is the kernel's own counted s_waitcnt + barrier.
+DEVINL void glds16_raw(const void* src, char* lds_dst_uniform) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(lds_void*)lds_dst_uniform;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
 
 // LDS image of an operand tile: [rows][BKT k] bf16, 16-B chunk c of row r stored at chunk position c ^ swz(r), chosen
 // so that every ds_read_b128 lane group ({0-3,12-15,20-27}, ...: 8 rows x chunk c + 8 rows x chunk c^1) covers all 16
@@ -71,7 +82,7 @@ DEVINL void tn_stage(const bf16_t* G, int64_t ld, int64_t r0, int64_t r_end, int
         const int64_t grow = r0 + row;
         const void* src = (grow < r_end) ? (const void*)(G + grow * ld + n0 + chunk * 8)
                                          : (const void*)((const char*)g_m3ae_zero_page + (lane & 15) * 16);
-        glds16(src, tile + seg * 1024);
+        glds16_raw(src, tile + seg * 1024);
     }
 }
 
