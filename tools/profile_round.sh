@@ -17,10 +17,10 @@ step() {  # name timeout cmd...
 : > $out/steps.log
 step bench 600 python bench.py
 grep '^{' $out/bench.log | tail -1 > $out/bench_line.json
-step stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 5 --warmup 3
-step fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
-step write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc -o write -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
-step mfma 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -o mfma -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 2 --warmup 1
+step stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --no-parity --steps 5 --warmup 3
+step fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o fetch -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --no-parity --steps 2 --warmup 1
+step write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc -o write -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --no-parity --steps 2 --warmup 1
+step mfma 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -o mfma -- python bench.py --no-cpu-baseline --no-roofline --no-secondary --no-parity --steps 2 --warmup 1
 # the fused cross-attention forward alone (north_star's kernel): kernel times and fabric-side bytes per layer pair
 step xattn_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/xattn_stats -o run -- python tools/xattn_pair.py
 step xattn_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o xfetch -- python tools/xattn_pair.py
