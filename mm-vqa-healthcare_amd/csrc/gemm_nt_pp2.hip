@@ -45,56 +45,96 @@ DEVINL void glds16_asm(const void* base, unsigned voff, unsigned dst) {
 // chunk c ^ r: the accumulator-layout writes (lane = row, 4 columns) and the row-contiguous reads (8 lanes = one row, 8 columns
 // each) are both bank-conflict free without padding.  LDS operations of one wave execute in order: no waits between the slab's
 // writes and reads beyond the data dependences hipcc tracks itself.
+// The epilogue's own loads (bias, residual / derivative operand) are issued from inline asm as well, and waited for by ONE counted
+// s_waitcnt of the kernel's own.  As compiler-visible loads they sat under run-time conditions (operand present, row in range), and so
+// did their consumers; hipcc merges those paths conservatively and (the .s of the first pp2 build shows it) put
+//   - s_waitcnt vmcnt(0) in front of the bias add and the residual add of EVERY one of the 16 row blocks of the epilogue: each block
+//     waited for the previous block's output stores to be acknowledged (and for the next tile's prefetch to land), and
+//   - s_waitcnt vmcnt(0) in front of the first fragment read of the next tile that reused one of those registers: the three
+//     chunks prefetched ahead and the epilogue's stores were drained at every tile start, behind the counted wait meant to keep
+//     them in flight.
+// Now: loads (unconditional, addresses clamped into the operand: rows / columns past the edge are loaded but never used) ->
+// the next tile's 16 prefetch pieces -> first slab writes -> s_waitcnt vmcnt(16) (vmcnt retires in order: the loads are the
+// older operations) -> 16 row blocks that only compute and store.
 template <typename TC, int EPI>
 struct EpiLoads {
-    float bias8[8];
+    u32x4 bias[2];
     u32x4 pre[8][2];
-    bool has_pre;
+    bool has_bias, has_pre;
 };
+
+DEVINL void gload16_asm(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+DEVINL void gload16_asm_nt(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(d) : "v"(p) : "memory"); }
 
 template <typename TC, int EPI>
 DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t n_base, EpiLoads<TC, EPI>& L) {
     constexpr bool BF = sizeof(TC) == 2;
     constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_DMUL);
-    const int64_t ncol = n_base + (lane & 7) * 8;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) L.bias8[t] = 0.f;
-    if (a.bias && ncol < a.N) Vec8<float>::ld(a.bias + ncol, L.bias8);
+    int64_t ncol = n_base + (lane & 7) * 8;
+    ncol = ncol < a.N ? ncol : 0;   // N % 8 == 0: a lane's 8 columns are all inside or all outside
+    L.bias[0] = L.bias[1] = (u32x4){0u, 0u, 0u, 0u};
+    L.has_bias = a.bias != nullptr;
+    if (L.has_bias) {
+        gload16_asm(L.bias[0], a.bias + ncol);
+        gload16_asm(L.bias[1], a.bias + ncol + 4);
+    }
     const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
     L.has_pre = BF && src != nullptr;
-    const bool nt_loads = a.st_policy >= 3;   // the residual / derivative operand is read once: streaming policy
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int p = 0; p < 2; ++p) L.pre[i][p] = (u32x4){0u, 0u, 0u, 0u};
     if (L.has_pre) {
+        const int64_t m_last = a.M - 1;
+        if (a.st_policy >= 3) {   // the residual / derivative operand is read once: streaming policy
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int64_t m = m_base + 16 * i + p * 8 + (lane >> 3);
-                if (m < a.M && ncol < a.N) {
-                    if (nt_loads) {   // (the empty asm statements keep hipcc from merging the two arms into one plain load)
-                        asm volatile("" ::: "memory");
-                        L.pre[i][p] = __builtin_nontemporal_load((const u32x4*)(src + m * a.ldc + ncol));
-                        asm volatile("" ::: "memory");
-                    } else {
-                        L.pre[i][p] = *(const u32x4*)(src + m * a.ldc + ncol);
-                    }
+                for (int p = 0; p < 2; ++p) {
+                    const int64_t m = m_base + 16 * i + p * 8 + (lane >> 3);
+                    gload16_asm_nt(L.pre[i][p], src + (m < m_last ? m : m_last) * a.ldc + ncol);
                 }
-            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int64_t m = m_base + 16 * i + p * 8 + (lane >> 3);
+                    gload16_asm(L.pre[i][p], src + (m < m_last ? m : m_last) * a.ldc + ncol);
+                }
+        }
     }
+}
+
+// younger = the prefetch pieces issued behind the loads (16, or none behind the last tile)
+template <typename TC, int EPI>
+DEVINL void epi_wait_loads(EpiLoads<TC, EPI>& L, bool prefetched) {
+    if (prefetched) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the loaded registers are "redefined" behind the wait: nothing that reads them can be scheduled in front of it
+    asm volatile("" : "+v"(L.bias[0]), "+v"(L.bias[1]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(L.pre[i][0]), "+v"(L.pre[i][1]));
 }
 
 template <typename TC, int EPI>
 DEVINL void epi_finish(const MfmaArgs& a, float* slab, int lane, int64_t m_base, int64_t n_base, f32x4 (&acc)[8][4],
-                       const EpiLoads<TC, EPI>& L) {
+                       EpiLoads<TC, EPI>& L, bool prefetched) {
     const int wrow = lane & 15, wq = lane >> 4;
     const int rq = lane & 7;
+    float bias8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) *(f32x4*)(slab + wrow * 64 + (((4 * j + wq) ^ wrow) << 2)) = acc[i][j];
+        if (i == 0) {
+            epi_wait_loads(L, prefetched);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {   // (through a copy: __builtin_bit_cast of a vector-element lvalue reads element 0, hipcc 7.2)
+                const u32x4 v = L.bias[t >> 2];
+                bias8[t] = __uint_as_float(v[t & 3]);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int row = p * 8 + (lane >> 3);
@@ -102,7 +142,7 @@ DEVINL void epi_finish(const MfmaArgs& a, float* slab, int lane, int64_t m_base,
             const f32x4 v1 = *(const f32x4*)(slab + row * 64 + (((2 * rq + 1) ^ row) << 2));
             float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const int64_t m = m_base + 16 * i + row, n = n_base + rq * 8;
-            if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x, L.bias8, L.has_pre, L.pre[i][p]);
+            if (m < a.M && n < a.N) epilogue8<TC, EPI>(a, m, n, x, bias8, L.has_pre, L.pre[i][p]);
         }
     }
 }
@@ -183,7 +223,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
         if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // stagger the second wave row by one barrier
 
         for (int c = 0; c < nc; ++c) {
-            const char* At = smem + (c & 3) * SLOT;
+            // the slot's byte offset is kept opaque: hipcc peels the first three chunks (their waits differ) and, knowing the slot there,
+            // materialises one address VGPR per fragment for the slots beyond the 64-KiB reach of the ds_read offset field (~12 VGPRs
+            // held across the whole kernel; with the epilogue's 200+ live registers that meant spill reloads inside the main loop)
+            unsigned slot_off = (unsigned)(c & 3) * SLOT;
+            asm volatile("" : "+s"(slot_off));
+            const char* At = smem + slot_off;
             const char* Bt = At + A_BYTES;
             const bool issue = c >= 1 && c + 3 < nc;   // chunk c + 3 -> the slot of chunk c - 1 (read in the previous phase; every
                                                        // wave's reads were retired by its lgkmcnt(0) BEFORE a barrier this wave passed)
@@ -263,12 +308,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
             EpiLoads<float, EPI> L;
             epi_issue_loads<float, EPI>(a, lane_e, m_cur, n_cur, L);
             prefetch_next();
-            epi_finish<float, EPI>(a, slab, lane_e, m_cur, n_cur, acc, L);
+            epi_finish<float, EPI>(a, slab, lane_e, m_cur, n_cur, acc, L, again);
         } else {
             EpiLoads<bf16_t, EPI> L;
             epi_issue_loads<bf16_t, EPI>(a, lane_e, m_cur, n_cur, L);
             prefetch_next();
-            epi_finish<bf16_t, EPI>(a, slab, lane_e, m_cur, n_cur, acc, L);
+            epi_finish<bf16_t, EPI>(a, slab, lane_e, m_cur, n_cur, acc, L, again);
         }
         if (!again) break;
         s_prev = interior ? s_interior : 0;
