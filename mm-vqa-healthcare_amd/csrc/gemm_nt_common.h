@@ -156,6 +156,12 @@ template <> struct Vec8<bf16_t> {
 // bias8: the 8 bias values of columns n .. n + 7 (preloaded once per wave); pre: the 16 bytes of the residual (or,
 // for the dact classes, of dact_aux) at (m, n .. n + 7), fetched before the LDS transposes so that the epilogue pays
 // the global-load latency once per wave instead of once per 32-row pass (bf16 C only; nullptr = load here).
+// 16-B global loads from inline asm: invisible to hipcc's vmcnt bookkeeping, so the kernel places its own (counted) wait and fences
+// the destination registers behind it with an empty asm that "redefines" them.  The destination is tied ("+v"): a load skipped on a
+// wave-uniform condition leaves the caller's initial value.
+DEVINL void gload16_asm(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+DEVINL void gload16_asm_nt(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(d) : "v"(p) : "memory"); }
+
 template <typename TC, int EPI>
 DEVINL void epilogue8(const MfmaArgs& a, int64_t m, int64_t n, float* x, const float* bias8, bool has_pre,
                       const u32x4 pre) {
@@ -232,10 +238,17 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
     constexpr bool BF = sizeof(TC) == 2;
     constexpr bool PRE_IS_AUX = (EPI == EPI_DGELU || EPI == EPI_DQGELU || EPI == EPI_DMUL);
     float* t = (float*)smem + wave * (16 * RT) * LDW;
-    const int64_t ncol = n_base + (lane & 7) * 8;
-    // everything the epilogue reads from global memory is requested up front: the wave waits for DRAM once
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.bias && ncol < a.N) Vec8<float>::ld(a.bias + ncol, bias8);
+    int64_t ncol = n_base + (lane & 7) * 8;
+    ncol = ncol < a.N ? ncol : 0;   // N % 8 == 0 on this path: a lane's 8 columns are all inside or all outside
+    // Everything the epilogue reads from global memory is requested up front, from inline asm, and waited for ONCE (gload16_asm):
+    // as compiler-visible loads under run-time conditions they made hipcc put s_waitcnt vmcnt(0) in front of the bias add and the
+    // residual add of every row pass, i.e. every pass waited for the previous pass's output stores to be acknowledged.
+    // Addresses are clamped into the operand: rows / columns past the edge are loaded but never used.
+    // (EPI_ANY, the catch-all instantiation, spills registers: a spill between an asm load and its wait would save a register whose
+    // load is still in flight -- it keeps compiler-visible loads; m3ae_amd/build.py refuses a build in which any OTHER instantiation
+    // of a kernel with asm loads spills.)
+    constexpr bool ASM_LOADS = EPI != EPI_ANY;
+    u32x4 bias_v[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
     const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
     const bool has_pre = BF && src != nullptr;
     u32x4 pre[MI / RT][2 * RT];
@@ -243,15 +256,37 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
     for (int half = 0; half < MI / RT; ++half)
 #pragma unroll
         for (int pass = 0; pass < 2 * RT; ++pass) pre[half][pass] = (u32x4){0u, 0u, 0u, 0u};
-    if (has_pre) {
+    if (ASM_LOADS) {
+        if (a.bias) {
+            gload16_asm(bias_v[0], a.bias + ncol);
+            gload16_asm(bias_v[1], a.bias + ncol + 4);
+        }
+        if (has_pre) {
+            const int64_t m_last = a.M - 1;
 #pragma unroll
-        for (int half = 0; half < MI / RT; ++half)
+            for (int half = 0; half < MI / RT; ++half)
 #pragma unroll
-            for (int pass = 0; pass < 2 * RT; ++pass) {
-                const int64_t m = m_base + 16 * RT * half + pass * 8 + (lane >> 3);
-                if (m < a.M && ncol < a.N) pre[half][pass] = *(const u32x4*)(src + m * a.ldc + ncol);
-            }
+                for (int pass = 0; pass < 2 * RT; ++pass) {
+                    const int64_t m = m_base + 16 * RT * half + pass * 8 + (lane >> 3);
+                    gload16_asm(pre[half][pass], src + (m < m_last ? m : m_last) * a.ldc + ncol);
+                }
+        }
+    } else {
+        if (a.bias) {
+            bias_v[0] = *(const u32x4*)(a.bias + ncol);
+            bias_v[1] = *(const u32x4*)(a.bias + ncol + 4);
+        }
+        if (has_pre) {
+#pragma unroll
+            for (int half = 0; half < MI / RT; ++half)
+#pragma unroll
+                for (int pass = 0; pass < 2 * RT; ++pass) {
+                    const int64_t m = m_base + 16 * RT * half + pass * 8 + (lane >> 3);
+                    if (m < a.M) pre[half][pass] = *(const u32x4*)(src + m * a.ldc + ncol);
+                }
+        }
     }
+    float bias8[8];
 #pragma unroll
     for (int half = 0; half < MI / RT; ++half) {
 #pragma unroll
@@ -259,6 +294,21 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(f32x4*)(t + (16 * ii + (lane & 15)) * LDW + 16 * j + 4 * (lane >> 4)) = acc[RT * half + ii][j];
+        if (half == 0) {   // the loads' latency runs under the first slab writes
+            if (ASM_LOADS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(bias_v[0]), "+v"(bias_v[1]));   // "redefined" behind the wait: no reader can be scheduled in front of it
+#pragma unroll
+                for (int hh = 0; hh < MI / RT; ++hh)
+#pragma unroll
+                    for (int pass = 0; pass < 2 * RT; ++pass) asm volatile("" : "+v"(pre[hh][pass]));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {   // (through a copy: __builtin_bit_cast of a vector-element lvalue reads element 0, hipcc 7.2)
+                const u32x4 v = bias_v[q >> 2];
+                bias8[q] = __uint_as_float(v[q & 3]);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int pass = 0; pass < 2 * RT; ++pass) {

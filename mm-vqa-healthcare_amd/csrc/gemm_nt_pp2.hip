@@ -63,9 +63,6 @@ struct EpiLoads {
     bool has_bias, has_pre;
 };
 
-DEVINL void gload16_asm(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
-DEVINL void gload16_asm_nt(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(d) : "v"(p) : "memory"); }
-
 template <typename TC, int EPI>
 DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t n_base, EpiLoads<TC, EPI>& L) {
     constexpr bool BF = sizeof(TC) == 2;
@@ -74,18 +71,34 @@ DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t
     ncol = ncol < a.N ? ncol : 0;   // N % 8 == 0: a lane's 8 columns are all inside or all outside
     L.bias[0] = L.bias[1] = (u32x4){0u, 0u, 0u, 0u};
     L.has_bias = a.bias != nullptr;
-    if (L.has_bias) {
-        gload16_asm(L.bias[0], a.bias + ncol);
-        gload16_asm(L.bias[1], a.bias + ncol + 4);
-    }
     const TC* src = (const TC*)(PRE_IS_AUX ? a.dact_aux : a.residual);
     L.has_pre = BF && src != nullptr;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int p = 0; p < 2; ++p) L.pre[i][p] = (u32x4){0u, 0u, 0u, 0u};
+    const int64_t m_last = a.M - 1;
+    if (EPI == EPI_ANY) {   // the catch-all instantiation spills registers: compiler-visible loads (see gemm_nt_common.h, epilogue_rows)
+        if (L.has_bias) {
+            L.bias[0] = *(const u32x4*)(a.bias + ncol);
+            L.bias[1] = *(const u32x4*)(a.bias + ncol + 4);
+        }
+        if (L.has_pre) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int64_t m = m_base + 16 * i + p * 8 + (lane >> 3);
+                    L.pre[i][p] = *(const u32x4*)(src + (m < m_last ? m : m_last) * a.ldc + ncol);
+                }
+        }
+        return;
+    }
+    if (L.has_bias) {
+        gload16_asm(L.bias[0], a.bias + ncol);
+        gload16_asm(L.bias[1], a.bias + ncol + 4);
+    }
     if (L.has_pre) {
-        const int64_t m_last = a.M - 1;
         if (a.st_policy >= 3) {   // the residual / derivative operand is read once: streaming policy
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -109,6 +122,7 @@ DEVINL void epi_issue_loads(const MfmaArgs& a, int lane, int64_t m_base, int64_t
 // younger = the prefetch pieces issued behind the loads (16, or none behind the last tile)
 template <typename TC, int EPI>
 DEVINL void epi_wait_loads(EpiLoads<TC, EPI>& L, bool prefetched) {
+    if (EPI == EPI_ANY) return;   // compiler-visible loads: hipcc places the waits
     if (prefetched) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the loaded registers are "redefined" behind the wait: nothing that reads them can be scheduled in front of it

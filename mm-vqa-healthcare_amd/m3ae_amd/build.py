@@ -25,6 +25,37 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
          f"-I{INC}", f"-I{CSRC}"] + EXTRA
 
 
+# Kernels whose epilogue operands are loaded from inline asm and waited for by the kernel's own s_waitcnt (gemm_nt_common.h:
+# gload16_asm): between such a load and its wait the destination registers are in flight, and a register spill there would save
+# garbage.  hipcc cannot know; this build checks instead: every instantiation of these kernels except the catch-all epilogue class
+# (EPI_ANY = 5, which keeps compiler-visible loads) must come out without scratch memory.
+ASM_LOAD_SOURCES = {"gemm_nt_pp2.hip": r"gemm_nt_pp2_kernel", "gemm_mfma.hip": r"gemm_nt_(bf16|pp|pp_persistent)_kernel"}
+REMARK = "-Rpass-analysis=kernel-resource-usage"
+
+
+def check_no_scratch(src_name, hipcc_output):
+    """Parse hipcc's kernel-resource-usage remarks of one source; raise if a kernel with asm loads uses scratch."""
+    import re
+    pat = re.compile(ASM_LOAD_SOURCES[src_name])
+    name, seen, bad = None, 0, []
+    for line in hipcc_output.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and pat.search(name):
+            seen += 1
+            if int(m.group(1)) and not re.search(r"Li5E+v", name):   # ...<..., EPI_ANY>: visible loads, may spill
+                bad.append((name, int(m.group(1))))
+    if not seen:
+        raise RuntimeError(f"{src_name}: no kernel-resource-usage remarks for {ASM_LOAD_SOURCES[src_name]} (hipcc output format changed?)")
+    if bad:
+        raise RuntimeError(f"{src_name}: kernels with inline-asm epilogue loads use scratch memory (a spill between an asm load and "
+                           f"its wait would save an in-flight register): {bad}")
+    return seen
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -47,7 +78,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OUT_DIR, s[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *([REMARK] if s in ASM_LOAD_SOURCES else []), "-c", src, "-o", obj])
 
     def run(cmd):
         p = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,6 +91,14 @@ def build(force=False, verbose=True):
                     print("[m3ae build]", os.path.basename(cmd[-3]), "rc =", rc, flush=True)
                 if rc != 0:
                     raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+                if os.path.basename(cmd[-3]) in ASM_LOAD_SOURCES and not EXTRA:
+                    try:
+                        n = check_no_scratch(os.path.basename(cmd[-3]), out)
+                    except RuntimeError:
+                        os.remove(cmd[-1])   # never link (or keep as up to date) an object that failed the check
+                        raise
+                    if verbose:
+                        print(f"[m3ae build] {os.path.basename(cmd[-3])}: {n} kernels with asm epilogue loads, none uses scratch", flush=True)
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         cmd, rc, out = run(cmd)

@@ -83,7 +83,7 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
 
 
 @pytest.mark.parametrize("variant", [7, 8, 9, 10, -1])
-@pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul", "dropout+res"])
+@pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul", "dropout+res", "tanh+pre+res", "dgelu+res"])
 def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant, kind):
     """The step's dominant kernel -- gemm_nt_pp2_kernel (round 4: 9, its persistent launch 10; what the auto rule (-1) picks for
     large shapes) and its predecessors gemm_nt_pp_kernel (7) / persistent (8) -- against an INDEPENDENT fp32 torch reference on the same bf16-rounded operands, every epilogue class,
@@ -116,6 +116,17 @@ def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant,
         elif kind == "dmul":
             ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_MULAUX)
             ref = pre * aux.float()
+        elif kind == "tanh+pre+res":   # the catch-all epilogue class (EPI_ANY: the instantiation that keeps compiler-visible loads)
+            extra = torch.empty_like(y)
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, act=ops.ACT_TANH, preact=extra, residual=aux)
+            ref = torch.tanh(pre + b) + aux.float()
+            close(extra, pre + b, 1e-2, 2e-2, msg="pre-activation")
+        elif kind == "dgelu+res":      # derivative operand prefetched, residual read inside the row passes
+            aux2 = rnd(M, N, dtype=torch.bfloat16, seed=35)
+            ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_GELU, residual=aux2)
+            u = aux.double()
+            cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+            ref = (pre + aux2.float()) * (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)).float()   # m3ae_hip.h: residual first
         else:
             keep = ops.dropout_keep_mask(M, N, 0.1, 4242)   # the exported mask of (p, seed) on an [M, N] array
             ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, bias=b, residual=aux, dropout=(0.1, 4242))

@@ -34,7 +34,7 @@ def time_it(fn, iters=ITERS):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else ""
     B = int(os.environ.get("B", 256))
-    m, dev = B * 577, "cuda"
+    m, dev = int(os.environ.get("M", B * 577)), "cuda"   # M=8192: the text side's rows at per-GPU batch 256
     cases = [(2304, 768, "plain"), (2304, 768, "bias"), (768, 768, "bias+res+drop"), (3072, 768, "gelu+deriv"), (3072, 768, "qgelu+pre"),
              (768, 3072, "bias+res+drop"), (3072, 768, "dmul"), (3072, 768, "dgelu"), (768, 3072, "plain"), (768, 768, "plain"), (768, 2304, "plain")]
     if SHAPES:
