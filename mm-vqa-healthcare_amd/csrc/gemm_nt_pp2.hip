@@ -278,8 +278,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
                 PP_FENCE();
                 __builtin_amdgcn_s_barrier();
                 PP_FENCE();
+#ifndef M3AE_EXP_PP2_HALFREADS   // timing experiment (wrong results): the second phase reuses the first phase's A fragments = the LDS
+                                 // read traffic of a 128 x 128-per-wave layout (8 instead of 12 KiB per wave and chunk)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i] = nt_frag<CK>(At, wr * 128 + 64 + i * 16 + frow, fchunk);
+#endif
                 if (issue) issue_a(c + 3);
                 wait_next();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the barrier: measured the same as behind it, and
