@@ -22,6 +22,14 @@
 
 using namespace m3g;
 
+#ifdef M3AE_EXP_PP2_CLOCK   // diagnostic build only (tools/nt_clock.py): the clock the chip holds inside this kernel (MI355X_MICROARCH.md,
+                            // 'DVFS give-back' item 6): shader cycles (s_memtime) over 100-MHz ticks (s_memrealtime) across the tile loop
+__device__ uint64_t g_pp2_clock[2 * 256];
+extern "C" int m3ae_diag_pp2_clock(uint64_t* out, int n) {   // n <= 512 values: [workgroup][cycles, ticks]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp2_clock), (size_t)n * sizeof(uint64_t)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 namespace {
 
 // wait until at most base + s (s = 0 / 16 / 32: the stores of the previous tile's epilogue, wave-uniform) vector-memory operations
@@ -161,8 +169,21 @@ DEVINL void epi_finish(const MfmaArgs& a, float* slab, int lane, int64_t m_base,
     }
 }
 
-template <int EPI>
+// PIPE: the software-pipelined main loop (round 4, second half).  Each wave requests the fragments of the NEXT 16-MFMA group before it
+// issues the current group (double-buffered B and A fragments: +32 VGPRs, live only in the main loop), so that behind a barrier a
+// wave can issue MFMAs at once instead of starting with its fragment reads; ONE barrier per 32-deep chunk instead of four:
+//     [read A1(c)]  G1(c) = A0(c) x B(c)   wait own pieces of chunk c + 1; barrier;  [DMA chunk c + 3: wave row 0]
+//     [read B(c + 1), A0(c + 1)]  G2(c) = A1(c) x B(c)   [DMA chunk c + 3: wave row 1]
+// Behind the barrier every wave has issued G1(c), i.e. has retired its reads of chunk c - 1 (the last of them, A1(c - 1), before
+// G2(c - 1)): the slot of chunk c - 1 is free for chunk c + 3; chunk c + 1 is read only behind the barrier.  The two wave rows
+// issue their DMA on opposite sides of G2, so one wave per SIMD computes while the other pays the ~60 clocks per piece.
+// Same MFMA order per accumulator as the unpipelined loop: bit-identical results.
+// MODE 2 (PPF): the ping-pong schedule (four barriers per chunk, wave rows staggered by one barrier: one wave per SIMD computes while
+// the other fetches) WITH the fragments of a wave's next group requested before its current group, so that a wave's segment between
+// two of its MFMA clusters is DMA issue + waits only, not fragment-read latency.
+template <int EPI, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
+    constexpr bool PIPE = MODE == 1, PPF = MODE == 2;
     if (a.has_drop) drop_resolve(a.drop);
     constexpr int CK = 32, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES, RING = 4 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,8 +217,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
     const bf16_t *abase, *bbase;
     unsigned va0, va1, vb0, vb1;
     auto set_ptrs = [&]() {
-        const int r0 = wave * 16 + (lane >> 2), r1 = r0 + 128;
-        const unsigned c0 = (unsigned)(((lane & 3) ^ nt_swz<CK>(r0)) * 16), c1 = (unsigned)(((lane & 3) ^ nt_swz<CK>(r1)) * 16);
+        int lane_p = lane;   // opaque copy: the lane-dependent parts are recomputed per tile, not carried through the main loop
+        asm volatile("" : "+v"(lane_p));
+        const int r0 = wave * 16 + (lane_p >> 2), r1 = r0 + 128;
+        const unsigned c0 = (unsigned)(((lane_p & 3) ^ nt_swz<CK>(r0)) * 16), c1 = (unsigned)(((lane_p & 3) ^ nt_swz<CK>(r1)) * 16);
         const int ma = (int)(a.M - 1 - m0 < 255 ? a.M - 1 - m0 : 255), mb = (int)(a.N - 1 - n0 < 255 ? a.N - 1 - n0 : 255);
         abase = a.A + m0 * a.lda;
         bbase = a.B + n0 * a.ldb;
@@ -221,6 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
     set_ptrs();
     for (int c = 0; c < npre; ++c) { issue_b(c); issue_a(c); }
 
+#ifdef M3AE_EXP_PP2_CLOCK
+    const uint64_t clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int s_prev = 0;   // stores the previous tile's epilogue issued behind this tile's prefetch (counted only when known exactly)
     const int s_interior = a.c_f32 || a.accumulate ? 0 : (a.preact ? 32 : 16);
     for (;;) {
@@ -234,8 +260,118 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
         PP_FENCE();
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
-        if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // stagger the second wave row by one barrier
+        if (!PIPE && wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // stagger the second wave row by one barrier
 
+        if (PPF) {
+            const int offB = nt_frag_off<CK>(wc * 64 + frow, fchunk) + A_BYTES;
+            const int offA = nt_frag_off<CK>(wr * 128 + frow, fchunk);
+            auto rd4 = [&](s16x8 (&f)[4], const char* base) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = *(const s16x8*)(base + j * 1024);
+            };
+            auto group = [&](const s16x8 (&bf)[4], const s16x8 (&af)[4], int half) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 * half + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto bar = [&]() { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); };
+            s16x8 b0[4], b1[4], a0[4], a1[4];
+            auto step = [&](int c, const s16x8 (&bc)[4], s16x8 (&bn)[4]) {
+                unsigned slot_off = (unsigned)(c & 3) * SLOT, slot_nxt = (unsigned)((c + 1) & 3) * SLOT;
+                asm volatile("" : "+s"(slot_off), "+s"(slot_nxt));
+                const bool issue = c >= 1 && c + 3 < nc;
+                // own pieces of chunk c + 1 landed -- in front of THIS phase's first barrier: the other wave row reads the chunk one
+                // barrier later than that row's own wait (younger: chunk c + 2, chunk 3 at c = 0, the previous epilogue's stores)
+                if (c + 1 < nc) {
+                    if (c == 0) wait_vm_s<8>(s_prev);
+                    else if (c < 3) wait_vm_s<4>(s_prev);
+                    else if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                rd4(a1, smem + slot_off + offA + 4096);   // A1(c)
+                if (issue) issue_b(c + 3);
+                bar();
+                group(bc, a0, 0);
+                bar();
+                rd4(bn, smem + slot_nxt + offB);          // B(c + 1), A0(c + 1): unconditional (behind the last chunk: stale, unused)
+                rd4(a0, smem + slot_nxt + offA);
+                if (issue) issue_a(c + 3);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // A1(c) retired in front of a barrier: its slot's next DMA is ordered
+                bar();                                               // behind barriers every wave has passed
+                group(bc, a1, 1);
+                bar();
+            };
+            rd4(b0, smem + offB);
+            rd4(a0, smem + offA);
+            PP_FENCE();
+            for (int c = 0; c < nc; c += 2) {   // nc is even (host check)
+                step(c, b0, b1);
+                step(c + 1, b1, b0);
+            }
+        } else if (PIPE) {
+            const int offB = nt_frag_off<CK>(wc * 64 + frow, fchunk) + A_BYTES;   // + j * 1024: the swizzle depends on frow only
+            const int offA = nt_frag_off<CK>(wr * 128 + frow, fchunk);            // + (4 * half + i) * 1024
+            auto rd4 = [&](s16x8 (&f)[4], const char* base) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = *(const s16x8*)(base + j * 1024);
+            };
+            auto group = [&](const s16x8 (&bf)[4], const s16x8 (&af)[4], int half) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 * half + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            s16x8 b0[4], b1[4], a0[4], a1[4];
+            auto step = [&](int c, const s16x8 (&bc)[4], s16x8 (&bn)[4]) {
+                unsigned slot_off = (unsigned)(c & 3) * SLOT, slot_nxt = (unsigned)((c + 1) & 3) * SLOT;
+                asm volatile("" : "+s"(slot_off), "+s"(slot_nxt));
+                rd4(a1, smem + slot_off + offA + 4096);   // A1(c)
+                PP_FENCE();
+                group(bc, a0, 0);
+                PP_FENCE();
+                const bool more = c + 1 < nc;
+                if (more) {
+                    // own pieces of chunk c + 1 landed; younger = chunk c + 2 (+ chunk 3 at c = 0, + the previous epilogue's stores while
+                    // the chunk waited for is one of the four prefetched ahead of them)
+                    if (c == 0) wait_vm_s<8>(s_prev);
+                    else if (c < 3) wait_vm_s<4>(s_prev);
+                    else if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PP_FENCE();
+                    __builtin_amdgcn_s_barrier();
+                    PP_FENCE();
+                }
+                const bool issue = c >= 1 && c + 3 < nc;
+                if (issue && wr == 0) { issue_b(c + 3); issue_a(c + 3); }
+                // unconditional (behind the last chunk: stale data of a landed slot, never used): under a branch hipcc's lgkmcnt for G2
+                // assumes the reads were skipped and waits for them
+                rd4(bn, smem + slot_nxt + offB);      // B(c + 1)
+                rd4(a0, smem + slot_nxt + offA);      // A0(c + 1)   (a0's last readers, G1(c), are issued)
+                PP_FENCE();
+                group(bc, a1, 1);
+                PP_FENCE();
+                if (issue && wr == 1) { issue_b(c + 3); issue_a(c + 3); }
+            };
+            rd4(b0, smem + offB);
+            rd4(a0, smem + offA);
+            PP_FENCE();
+            for (int c = 0; c < nc; c += 2) {   // nc is even (host check)
+                step(c, b0, b1);
+                step(c + 1, b1, b0);
+            }
+            PP_FENCE();
+            __builtin_amdgcn_s_barrier();   // every fragment read of the tile is retired (each wave's last reads precede its last group)
+            PP_FENCE();
+        } else
         for (int c = 0; c < nc; ++c) {
             // the slot's byte offset is kept opaque: hipcc peels the first three chunks (their waits differ) and, knowing the slot there,
             // materialises one address VGPR per fragment for the slots beyond the 64-KiB reach of the ds_read offset field (~12 VGPRs
@@ -302,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
                 PP_FENCE();
             }
         }
-        if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // re-align: every fragment read of the tile is retired, no DMA
+        if (!PIPE && wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // re-align: every fragment read of the tile is retired, no DMA
                                                                      // of this tile is outstanding: all four slots are free
         const unsigned vn = v + gridDim.x;
         const bool again = vn < total;
@@ -332,19 +468,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
             prefetch_next();
             epi_finish<bf16_t, EPI>(a, slab, lane_e, m_cur, n_cur, acc, L, again);
         }
+#ifdef M3AE_EXP_PP2_CLOCK
+        if (!again && tid == 0 && blockIdx.x < 256) {
+            g_pp2_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_c0;
+            g_pp2_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        }
+#endif
         if (!again) break;
         s_prev = interior ? s_interior : 0;
         v = vn;
     }
 }
 
-template <int EPI>
+template <int EPI, int PIPE>
 int launch_pp2_t(const MfmaArgs& a, bool persistent, hipStream_t s) {
     constexpr int lds = 4 * (256 + 256) * 32 * 2 + 8 * 4096;   // 128-KiB ring + 8 slabs = all 160 KiB
     static bool attr_set = false;
     static int cus = 256;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int dev = 0;
         hipDeviceProp_t prop;
@@ -354,24 +496,29 @@ int launch_pp2_t(const MfmaArgs& a, bool persistent, hipStream_t s) {
     }
     const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
     const unsigned grid = (unsigned)(persistent && tiles > cus ? cus : tiles);
-    hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI, PIPE>), dim3(grid), dim3(512), lds, s, a);
     return hip_launch_status();
 }
 
+template <int PIPE>
 int launch_pp2_e(const MfmaArgs& a, int epi, bool persistent, hipStream_t s) {
     switch (epi) {
-        case EPI_PLAIN: return launch_pp2_t<EPI_PLAIN>(a, persistent, s);
-        case EPI_GELU: return launch_pp2_t<EPI_GELU>(a, persistent, s);
-        case EPI_QGELU: return launch_pp2_t<EPI_QGELU>(a, persistent, s);
-        case EPI_DGELU: return launch_pp2_t<EPI_DGELU>(a, persistent, s);
-        case EPI_DQGELU: return launch_pp2_t<EPI_DQGELU>(a, persistent, s);
-        case EPI_DMUL: return launch_pp2_t<EPI_DMUL>(a, persistent, s);
-        case EPI_RELU: return launch_pp2_t<EPI_RELU>(a, persistent, s);
-        default: return launch_pp2_t<EPI_ANY>(a, persistent, s);
+        case EPI_PLAIN: return launch_pp2_t<EPI_PLAIN, PIPE>(a, persistent, s);
+        case EPI_GELU: return launch_pp2_t<EPI_GELU, PIPE>(a, persistent, s);
+        case EPI_QGELU: return launch_pp2_t<EPI_QGELU, PIPE>(a, persistent, s);
+        case EPI_DGELU: return launch_pp2_t<EPI_DGELU, PIPE>(a, persistent, s);
+        case EPI_DQGELU: return launch_pp2_t<EPI_DQGELU, PIPE>(a, persistent, s);
+        case EPI_DMUL: return launch_pp2_t<EPI_DMUL, PIPE>(a, persistent, s);
+        case EPI_RELU: return launch_pp2_t<EPI_RELU, PIPE>(a, persistent, s);
+        default: return launch_pp2_t<EPI_ANY, 0>(a, persistent, s);   // the catch-all class keeps the unpipelined loop (it spills)
     }
 }
 
 }  // namespace
 
-// preconditions (checked by the caller, gemm_mfma.hip::launch_nt_v): rows_epi (N % 8 == 0, ldc % 8 == 0), K % 32 == 0, K >= 256, M, N > 128
-int m3g::launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, hipStream_t s) { return launch_pp2_e(a, epi, persistent, s); }
+// preconditions (checked by the caller, gemm_mfma.hip::launch_nt_v): rows_epi (N % 8 == 0, ldc % 8 == 0), K % 32 == 0, K >= 256, M, N > 128;
+// pipe additionally needs an even number of 32-deep chunks (K % 64 == 0), else the unpipelined loop runs
+int m3g::launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, int mode, hipStream_t s) {
+    if (a.K % 64 != 0) mode = 0;
+    return mode == 2 ? launch_pp2_e<2>(a, epi, persistent, s) : mode == 1 ? launch_pp2_e<1>(a, epi, persistent, s) : launch_pp2_e<0>(a, epi, persistent, s);
+}

@@ -46,7 +46,7 @@ def check_no_scratch(src_name, hipcc_output):
         m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name and pat.search(name):
             seen += 1
-            if int(m.group(1)) and not re.search(r"Li5E+v", name):   # ...<..., EPI_ANY>: visible loads, may spill
+            if int(m.group(1)) and not re.search(r"Li5E(L[bi][0-9]E)?E+v", name):   # ...<..., EPI_ANY>: visible loads, may spill
                 bad.append((name, int(m.group(1))))
     if not seen:
         raise RuntimeError(f"{src_name}: no kernel-resource-usage remarks for {ASM_LOAD_SOURCES[src_name]} (hipcc output format changed?)")
