@@ -669,15 +669,15 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         // data-parallel runs (M3AE_GEMM_NO_PERSISTENT) take the per-tile launch: static tile lists start late beside RCCL's kernels.
         if (big && a.rows_epi && a.K >= 256) {
             g_last_path = "mfma_nt_pp2";
-            return launch_nt_pp2(a, EPI, persist_ok && !a.no_persist, 0, s);
+            return launch_nt_pp2(a, EPI, persist_ok && !a.no_persist, s);
         }
         if (big && persist_ok && !a.no_persist && a.rows_epi && a.K >= 96) return launch_nt_pp_persistent<EPI>(a, s);  // +1..3 % (next tile's
         if (big) return launch_nt_pp<EPI>(a, s);                                                  // chunks under the epilogue)
         return launch_nt_t<128, 128, 64, 2, 64, EPI>(a, s);
     }
-    if (g_nt_variant >= 9 && g_nt_variant <= 14 && a.M > 128 && a.N > 128 && a.rows_epi && a.K >= 256) {   // gemm_nt_pp2.hip
+    if ((g_nt_variant == 9 || g_nt_variant == 10) && a.M > 128 && a.N > 128 && a.rows_epi && a.K >= 256) {   // gemm_nt_pp2.hip
         g_last_path = "mfma_nt_pp2";   // 9: grid = tiles; 10: persistent (grid = CUs)
-        return launch_nt_pp2(a, EPI, (g_nt_variant & 1) == 0, (g_nt_variant - 9) >> 1, s);   // 11 / 12: pipelined main loop; 13 / 14: ping-pong + prefetch
+        return launch_nt_pp2(a, EPI, g_nt_variant == 10, s);
     }
     if (g_nt_variant == 7 && a.M > 128 && a.N > 128) return launch_nt_pp<EPI>(a, s);  // ping-pong 8-phase
     if (g_nt_variant == 8 && a.rows_epi && a.K >= 96 && cdiv(a.M, 256) * cdiv(a.N, 256) >= 512)

@@ -324,6 +324,6 @@ DEVINL void epilogue_rows(const MfmaArgs& a, char* smem, int wave, int lane, int
 }
 
 // gemm_nt_pp2.hip: the second-generation ping-pong kernel (preconditions: rows_epi, K % 32 == 0, M, N > 128)
-int launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, int mode, hipStream_t s);   // mode 0 classic, 1 pipelined, 2 ping-pong + fragment prefetch
+int launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, hipStream_t s);
 
 }  // namespace m3g

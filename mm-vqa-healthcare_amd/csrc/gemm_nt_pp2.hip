@@ -169,21 +169,19 @@ DEVINL void epi_finish(const MfmaArgs& a, float* slab, int lane, int64_t m_base,
     }
 }
 
-// PIPE: the software-pipelined main loop (round 4, second half).  Each wave requests the fragments of the NEXT 16-MFMA group before it
-// issues the current group (double-buffered B and A fragments: +32 VGPRs, live only in the main loop), so that behind a barrier a
-// wave can issue MFMAs at once instead of starting with its fragment reads; ONE barrier per 32-deep chunk instead of four:
-//     [read A1(c)]  G1(c) = A0(c) x B(c)   wait own pieces of chunk c + 1; barrier;  [DMA chunk c + 3: wave row 0]
-//     [read B(c + 1), A0(c + 1)]  G2(c) = A1(c) x B(c)   [DMA chunk c + 3: wave row 1]
-// Behind the barrier every wave has issued G1(c), i.e. has retired its reads of chunk c - 1 (the last of them, A1(c - 1), before
-// G2(c - 1)): the slot of chunk c - 1 is free for chunk c + 3; chunk c + 1 is read only behind the barrier.  The two wave rows
-// issue their DMA on opposite sides of G2, so one wave per SIMD computes while the other pays the ~60 clocks per piece.
-// Same MFMA order per accumulator as the unpipelined loop: bit-identical results.
-// MODE 2 (PPF): the ping-pong schedule (four barriers per chunk, wave rows staggered by one barrier: one wave per SIMD computes while
-// the other fetches) WITH the fragments of a wave's next group requested before its current group, so that a wave's segment between
-// two of its MFMA clusters is DMA issue + waits only, not fragment-read latency.
-template <int EPI, int MODE>
+// Built, measured, NOT kept (round 4, second half; both bit-identical to this loop, in the tree at commit 39eb520 as variants 11-14):
+//  * a software-pipelined main loop -- every wave requests the fragments of its NEXT 16-MFMA group before issuing the current one
+//    (double-buffered B / A fragments, 253 VGPRs, no spills), ONE barrier per chunk, the two wave rows issuing their DMA on opposite
+//    sides of the second group: 9 % SLOWER over the step's eleven classes (profiles/r04_nt_pp2_pipelined_loop_ab.log);
+//  * this ping-pong schedule (four barriers, rows staggered) WITH that fragment prefetch, so that a wave's segment between two of its
+//    MFMA clusters is DMA issue + waits only: the SAME time (6554 vs 6583 us, profiles/r04_nt_pp2_pingpong_prefetch_ab.log);
+//  * a third fewer LDS fragment reads (timing-only build, wrong results): -2 % (profiles/r04_nt_pp2_half_lds_reads_timing.log).
+// Neither the fragment-read latency nor the barrier count bounds this loop.  What the chip does under it (tools/nt_clock.py,
+// profiles/r04_nt_in_kernel_clock.log): it holds 1.81-1.94 GHz on random data (2.38 GHz on zero-filled operands, +20 % TF/s at the same
+// cycle count), i.e. the kernel delivers 0.52 (K = 768) to 0.62 (K = 3072) of the bf16 MFMA rate AT THE CLOCK IT RUNS AT, and cycles
+// saved in the loop come back partly as a lower clock (MI355X_MICROARCH.md, 'DVFS give-back').
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
-    constexpr bool PIPE = MODE == 1, PPF = MODE == 2;
     if (a.has_drop) drop_resolve(a.drop);
     constexpr int CK = 32, A_BYTES = 256 * CK * 2, SLOT = 2 * A_BYTES, RING = 4 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -260,118 +258,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
         PP_FENCE();
         __builtin_amdgcn_s_barrier();
         PP_FENCE();
-        if (!PIPE && wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // stagger the second wave row by one barrier
+        if (wr == 1) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // stagger the second wave row by one barrier
 
-        if (PPF) {
-            const int offB = nt_frag_off<CK>(wc * 64 + frow, fchunk) + A_BYTES;
-            const int offA = nt_frag_off<CK>(wr * 128 + frow, fchunk);
-            auto rd4 = [&](s16x8 (&f)[4], const char* base) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = *(const s16x8*)(base + j * 1024);
-            };
-            auto group = [&](const s16x8 (&bf)[4], const s16x8 (&af)[4], int half) {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 * half + i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            };
-            auto bar = [&]() { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); };
-            s16x8 b0[4], b1[4], a0[4], a1[4];
-            auto step = [&](int c, const s16x8 (&bc)[4], s16x8 (&bn)[4]) {
-                unsigned slot_off = (unsigned)(c & 3) * SLOT, slot_nxt = (unsigned)((c + 1) & 3) * SLOT;
-                asm volatile("" : "+s"(slot_off), "+s"(slot_nxt));
-                const bool issue = c >= 1 && c + 3 < nc;
-                // own pieces of chunk c + 1 landed -- in front of THIS phase's first barrier: the other wave row reads the chunk one
-                // barrier later than that row's own wait (younger: chunk c + 2, chunk 3 at c = 0, the previous epilogue's stores)
-                if (c + 1 < nc) {
-                    if (c == 0) wait_vm_s<8>(s_prev);
-                    else if (c < 3) wait_vm_s<4>(s_prev);
-                    else if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                rd4(a1, smem + slot_off + offA + 4096);   // A1(c)
-                if (issue) issue_b(c + 3);
-                bar();
-                group(bc, a0, 0);
-                bar();
-                rd4(bn, smem + slot_nxt + offB);          // B(c + 1), A0(c + 1): unconditional (behind the last chunk: stale, unused)
-                rd4(a0, smem + slot_nxt + offA);
-                if (issue) issue_a(c + 3);
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // A1(c) retired in front of a barrier: its slot's next DMA is ordered
-                bar();                                               // behind barriers every wave has passed
-                group(bc, a1, 1);
-                bar();
-            };
-            rd4(b0, smem + offB);
-            rd4(a0, smem + offA);
-            PP_FENCE();
-            for (int c = 0; c < nc; c += 2) {   // nc is even (host check)
-                step(c, b0, b1);
-                step(c + 1, b1, b0);
-            }
-        } else if (PIPE) {
-            const int offB = nt_frag_off<CK>(wc * 64 + frow, fchunk) + A_BYTES;   // + j * 1024: the swizzle depends on frow only
-            const int offA = nt_frag_off<CK>(wr * 128 + frow, fchunk);            // + (4 * half + i) * 1024
-            auto rd4 = [&](s16x8 (&f)[4], const char* base) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = *(const s16x8*)(base + j * 1024);
-            };
-            auto group = [&](const s16x8 (&bf)[4], const s16x8 (&af)[4], int half) {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[4 * half + i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            };
-            s16x8 b0[4], b1[4], a0[4], a1[4];
-            auto step = [&](int c, const s16x8 (&bc)[4], s16x8 (&bn)[4]) {
-                unsigned slot_off = (unsigned)(c & 3) * SLOT, slot_nxt = (unsigned)((c + 1) & 3) * SLOT;
-                asm volatile("" : "+s"(slot_off), "+s"(slot_nxt));
-                rd4(a1, smem + slot_off + offA + 4096);   // A1(c)
-                PP_FENCE();
-                group(bc, a0, 0);
-                PP_FENCE();
-                const bool more = c + 1 < nc;
-                if (more) {
-                    // own pieces of chunk c + 1 landed; younger = chunk c + 2 (+ chunk 3 at c = 0, + the previous epilogue's stores while
-                    // the chunk waited for is one of the four prefetched ahead of them)
-                    if (c == 0) wait_vm_s<8>(s_prev);
-                    else if (c < 3) wait_vm_s<4>(s_prev);
-                    else if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    PP_FENCE();
-                    __builtin_amdgcn_s_barrier();
-                    PP_FENCE();
-                }
-                const bool issue = c >= 1 && c + 3 < nc;
-                if (issue && wr == 0) { issue_b(c + 3); issue_a(c + 3); }
-                // unconditional (behind the last chunk: stale data of a landed slot, never used): under a branch hipcc's lgkmcnt for G2
-                // assumes the reads were skipped and waits for them
-                rd4(bn, smem + slot_nxt + offB);      // B(c + 1)
-                rd4(a0, smem + slot_nxt + offA);      // A0(c + 1)   (a0's last readers, G1(c), are issued)
-                PP_FENCE();
-                group(bc, a1, 1);
-                PP_FENCE();
-                if (issue && wr == 1) { issue_b(c + 3); issue_a(c + 3); }
-            };
-            rd4(b0, smem + offB);
-            rd4(a0, smem + offA);
-            PP_FENCE();
-            for (int c = 0; c < nc; c += 2) {   // nc is even (host check)
-                step(c, b0, b1);
-                step(c + 1, b1, b0);
-            }
-            PP_FENCE();
-            __builtin_amdgcn_s_barrier();   // every fragment read of the tile is retired (each wave's last reads precede its last group)
-            PP_FENCE();
-        } else
         for (int c = 0; c < nc; ++c) {
             // the slot's byte offset is kept opaque: hipcc peels the first three chunks (their waits differ) and, knowing the slot there,
             // materialises one address VGPR per fragment for the slots beyond the 64-KiB reach of the ds_read offset field (~12 VGPRs
@@ -438,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
                 PP_FENCE();
             }
         }
-        if (!PIPE && wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // re-align: every fragment read of the tile is retired, no DMA
+        if (wr == 0) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }   // re-align: every fragment read of the tile is retired, no DMA
                                                                      // of this tile is outstanding: all four slots are free
         const unsigned vn = v + gridDim.x;
         const bool again = vn < total;
@@ -480,13 +368,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp2_kernel(MfmaArgs a) {
     }
 }
 
-template <int EPI, int PIPE>
+template <int EPI>
 int launch_pp2_t(const MfmaArgs& a, bool persistent, hipStream_t s) {
     constexpr int lds = 4 * (256 + 256) * 32 * 2 + 8 * 4096;   // 128-KiB ring + 8 slabs = all 160 KiB
     static bool attr_set = false;
     static int cus = 256;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI, PIPE>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int dev = 0;
         hipDeviceProp_t prop;
@@ -496,29 +384,24 @@ int launch_pp2_t(const MfmaArgs& a, bool persistent, hipStream_t s) {
     }
     const int64_t tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
     const unsigned grid = (unsigned)(persistent && tiles > cus ? cus : tiles);
-    hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI, PIPE>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI>), dim3(grid), dim3(512), lds, s, a);
     return hip_launch_status();
 }
 
-template <int PIPE>
 int launch_pp2_e(const MfmaArgs& a, int epi, bool persistent, hipStream_t s) {
     switch (epi) {
-        case EPI_PLAIN: return launch_pp2_t<EPI_PLAIN, PIPE>(a, persistent, s);
-        case EPI_GELU: return launch_pp2_t<EPI_GELU, PIPE>(a, persistent, s);
-        case EPI_QGELU: return launch_pp2_t<EPI_QGELU, PIPE>(a, persistent, s);
-        case EPI_DGELU: return launch_pp2_t<EPI_DGELU, PIPE>(a, persistent, s);
-        case EPI_DQGELU: return launch_pp2_t<EPI_DQGELU, PIPE>(a, persistent, s);
-        case EPI_DMUL: return launch_pp2_t<EPI_DMUL, PIPE>(a, persistent, s);
-        case EPI_RELU: return launch_pp2_t<EPI_RELU, PIPE>(a, persistent, s);
-        default: return launch_pp2_t<EPI_ANY, 0>(a, persistent, s);   // the catch-all class keeps the unpipelined loop (it spills)
+        case EPI_PLAIN: return launch_pp2_t<EPI_PLAIN>(a, persistent, s);
+        case EPI_GELU: return launch_pp2_t<EPI_GELU>(a, persistent, s);
+        case EPI_QGELU: return launch_pp2_t<EPI_QGELU>(a, persistent, s);
+        case EPI_DGELU: return launch_pp2_t<EPI_DGELU>(a, persistent, s);
+        case EPI_DQGELU: return launch_pp2_t<EPI_DQGELU>(a, persistent, s);
+        case EPI_DMUL: return launch_pp2_t<EPI_DMUL>(a, persistent, s);
+        case EPI_RELU: return launch_pp2_t<EPI_RELU>(a, persistent, s);
+        default: return launch_pp2_t<EPI_ANY>(a, persistent, s);
     }
 }
 
 }  // namespace
 
-// preconditions (checked by the caller, gemm_mfma.hip::launch_nt_v): rows_epi (N % 8 == 0, ldc % 8 == 0), K % 32 == 0, K >= 256, M, N > 128;
-// pipe additionally needs an even number of 32-deep chunks (K % 64 == 0), else the unpipelined loop runs
-int m3g::launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, int mode, hipStream_t s) {
-    if (a.K % 64 != 0) mode = 0;
-    return mode == 2 ? launch_pp2_e<2>(a, epi, persistent, s) : mode == 1 ? launch_pp2_e<1>(a, epi, persistent, s) : launch_pp2_e<0>(a, epi, persistent, s);
-}
+// preconditions (checked by the caller, gemm_mfma.hip::launch_nt_v): rows_epi (N % 8 == 0, ldc % 8 == 0), K % 32 == 0, K >= 256, M, N > 128
+int m3g::launch_nt_pp2(const MfmaArgs& a, int epi, bool persistent, hipStream_t s) { return launch_pp2_e(a, epi, persistent, s); }

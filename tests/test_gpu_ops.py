@@ -82,7 +82,7 @@ def test_gemm_mfma_matches_generic_bitwise_shape_sweep(variant):
     ops.GEMM_NT_VARIANT = -1
 
 
-@pytest.mark.parametrize("variant", [7, 8, 9, 10, 11, 12, 13, 14, -1])
+@pytest.mark.parametrize("variant", [7, 8, 9, 10, -1])
 @pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul", "dropout+res", "tanh+pre+res", "dgelu+res"])
 def test_gemm_nt_pingpong_and_persistent_vs_fp32_reference_large_ragged(variant, kind):
     """The step's dominant kernel -- gemm_nt_pp2_kernel (round 4: 9, its persistent launch 10; what the auto rule (-1) picks for
@@ -664,7 +664,7 @@ def test_gemm_epilogue_dropout_after_activation_and_in_dgrad(dtype):
 @pytest.mark.parametrize("kind", ["plain", "bias+res", "gelu+deriv", "dmul"])
 def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     """Every NT kernel the auto path or a tuning key can select for large shapes -- 256x256 2-stage (4), ping-pong (7), its
-    persistent form (8, >= 512 tiles), the second-generation kernel of round 4 (9, persistent launch 10, its software-pipelined main loop 11 / 12, auto -1) -- accumulates in the same order: on the
+    persistent form (8, >= 512 tiles), the second-generation kernel of round 4 (9, persistent launch 10, auto -1) -- accumulates in the same order: on the
     path's own large shapes and epilogue classes the bf16 outputs are identical, ragged row tail included."""
     from m3ae_amd import _lib
     L = _lib.lib()
@@ -675,7 +675,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
     aux = rnd(M, N, dtype=torch.bfloat16, seed=24)
     outs = {}
     try:
-        for v in (4, 7, 8, 9, 10, 11, 12, 13, 14, -1):
+        for v in (4, 7, 8, 9, 10, -1):
             ops.GEMM_NT_VARIANT = v
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             extra = None
@@ -690,7 +690,7 @@ def test_gemm_nt_kernels_agree_bit_for_bit_on_the_large_shapes(kind):
                 ops.gemm(x, K, 1, w, 1, K, y, N, M, N, K, dact_aux=aux, dact=ops.ACT_MULAUX)
             outs[v] = (y, extra, ops.last_gemm_path())
         assert outs[8][2] == "mfma_nt_pp" and outs[9][2] == outs[10][2] == outs[-1][2] == "mfma_nt_pp2"
-        for v in (7, 8, 9, 10, 11, 12, 13, 14, -1):
+        for v in (7, 8, 9, 10, -1):
             assert torch.equal(outs[v][0].view(torch.int16), outs[4][0].view(torch.int16)), (kind, v)
             if outs[4][1] is not None:
                 assert torch.equal(outs[v][1].view(torch.int16), outs[4][1].view(torch.int16)), (kind, v, "derivative")
