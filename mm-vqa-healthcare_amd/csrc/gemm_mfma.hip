@@ -989,9 +989,15 @@ static int launch_tn(const m3ae_gemm_desc& d, hipStream_t s) {
     const bool pp_ok = d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 4096;
     const int g_tn_variant = ((d.launch_flags >> 12) & 0xf) - 1;
     if (g_tn_variant == 5 && pp_ok) return launch_tn_pp(a, d, s);
-    if (g_tn_variant < 0) {  // auto (default), measured (profiles/r01_gemm_shapes.log): the ping-pong kernel wins on long
-        // reductions (+2..10 % at 147712 rows) and, from 32768 rows, on the large outputs only
-        if (pp_ok && (d.K >= 65536 || (d.K >= 32768 && d.M * d.N >= 768 * 3072))) return launch_tn_pp(a, d, s);
+    if (g_tn_variant < 0 || g_tn_variant == 6) {
+        // auto (default).  Re-measured in round 4 after both kernels' LDS-DMA moved to inline asm (mfma_tiles.h: the 128 x 128 kernel
+        // gained as much as the ping-pong one): the 256 x 256 ping-pong kernel wins on the 768 x 3072 / 3072 x 768 outputs from 65536
+        // reduction rows (+3..4 % at 110784-147712, equal at 73856) and nowhere else -- 2304 x 768 and 768 x 768 are equal at
+        // 147712 and 5-15 % SLOWER on it at 36928-110784, the large outputs 8 % slower at 36928
+        // (profiles/r04_tn_kernel_choice_by_batch.log).  Variant 6 = the rule of rounds 1-3, kept for A/B runs.
+        const bool r3_rule = pp_ok && (d.K >= 65536 || (d.K >= 32768 && d.M * d.N >= 768 * 3072));
+        const bool r4_rule = pp_ok && d.K >= 65536 && d.M * d.N >= 768 * 3072;
+        if (g_tn_variant == 6 ? r3_rule : r4_rule) return launch_tn_pp(a, d, s);
         return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);
     }
     if (g_tn_variant == 2) return launch_tn_t<128, 128, 64, 32, 2>(a, d, s);  // 32 KiB LDS: 3 workgroups / CU

@@ -9,7 +9,8 @@ from m3ae_amd import ops  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 B = int(os.environ.get("B", 256))
-m = B * 577
+m = int(os.environ.get("M", B * 577))   # M=1024: the text side's reduction at per-GPU batch 32
+ops.GEMM_TN_VARIANT = int(os.environ.get("TNVAR", -1))   # 5: the 256 x 256 ping-pong kernel where its preconditions hold; 2: 128 x 128
 
 
 def time_it(fn, iters=10):
