@@ -660,7 +660,9 @@ static int launch_nt_v(const MfmaArgs& a, hipStream_t s) {
         const int64_t t256 = cdiv(a.M, 256) * cdiv(a.N, 256), t128 = cdiv(a.M, 128) * cdiv(a.N, 128);
         const double eff256 = (double)t256 / (double)(cdiv(t256, 256) * 256);
         const double eff128 = (double)t128 / (double)(cdiv(t128, 512) * 512);
-        const bool big = a.M > 128 && a.N > 128 && eff256 >= 0.88 * eff128;
+        // (round 4, pp2 against the 128 x 128 kernel at 18464 rows: N = 3072 (0.855 vs 0.971) is 5-13 % faster on the 128 x 128 kernel,
+        // N = 768 / 2304 (0.855 vs 0.85) 4-19 % faster on pp2: the threshold moved from 0.88 to 0.93, profiles/r04_nt_kernel_choice_small_batch.log)
+        const bool big = a.M > 128 && a.N > 128 && eff256 >= 0.93 * eff128;
         const bool persist_ok = t256 >= 512;   // the persistent form pays from two full rounds on (+1..3 %)
         // second-generation ping-pong kernel (gemm_nt_pp2.hip): -2.2 % against the persistent kernel below over the step's eleven
         // shape / epilogue classes at per-GPU batch 256, -3.6 % against the one-tile-per-workgroup form data-parallel runs take
@@ -953,7 +955,14 @@ static int launch_tn_t(MfmaArgs a, const m3ae_gemm_desc& d, hipStream_t s) {
     constexpr int threads = (BM_ / WM) * (BN_ / 64) * 64;
     const int64_t tiles = (d.M / BM_) * (d.N / BN_);
     const int64_t ksteps = cdiv(d.K, 64);
-    const int64_t target = lds > 65536 ? 256 : 768;  // workgroups in flight: 1 or ~3 per CU
+#ifdef M3AE_EXP_TN_TARGET   // timing experiment: split-K fan-out of the 128 x 128 kernel (workgroups per launch)
+    const int64_t target = M3AE_EXP_TN_TARGET;
+#else
+    // workgroups in flight: 1 or ~3 per CU; a 768 x 768 output (36 tiles) is bound by its splits' fp32 atomic tiles, not by
+    // parallelism: 10-14 splits instead of 17-21 measured -10..17 % at 18464 / 36928 rows (profiles/r04_tn_split_fanout_small_batch.log)
+    // (long reductions keep the full fan-out: their atomics are a small share and 3 workgroups per CU balance better)
+    const int64_t target = lds > 65536 ? 256 : (tiles <= 48 && ksteps <= 1024 ? 448 : 768);
+#endif
     // >= 1024 reduction rows per split (K = 8192, 768 x 768: 42 -> 31.5 us).  Shorter splits on the short reductions of the text
     // stream at small per-GPU batches (1024-4096 rows) were measured in round 3 and LOSE: 256 rows per split took 37-43 us against
     // 24-32 us (profiles/r03_tn_small_batch.log): the extra workgroups' atomic tiles cost more than the parallelism buys

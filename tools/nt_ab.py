@@ -69,7 +69,7 @@ def main():
         ref, ref_pre = y.clone(), pre.clone()
         ident = {}
         for v in VARS:
-            ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = v % 100, v // 100
+            ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = (v % 100 if v >= 0 else -1), (v // 100 if v >= 0 else 0)
             y.fill_(float("nan")); pre.fill_(float("nan"))
             fn()
             torch.cuda.synchronize()
@@ -80,7 +80,7 @@ def main():
         res = {v: [] for v in VARS}
         for r in range(ROUNDS):
             for v in VARS:
-                ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = v % 100, v // 100
+                ops.GEMM_NT_VARIANT, ops.GEMM_ST_POLICY = (v % 100 if v >= 0 else -1), (v // 100 if v >= 0 else 0)
                 res[v].append(time_it(fn))
         line = []
         for v in VARS:
