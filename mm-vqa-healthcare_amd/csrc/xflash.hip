@@ -220,11 +220,14 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
     // --------------------------------------------------------------------------------------------------- compute waves
     const int wr = wave >> 2, wc = wave & 3;
     const bool late = wave >= 4;
-    int aoff[MI], boff1[NJ1];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) aoff[i] = nt_frag_off<32>(wr * WM + i * 16 + (lane & 15), lane >> 4);
-#pragma unroll
-    for (int j = 0; j < NJ1; ++j) boff1[j] = A1_BYTES + nt_frag_off<32>(wc * WN1 + j * 16 + (lane & 15), lane >> 4);
+    // fragment byte offsets: ONE per-lane register per operand, the 16-row steps as immediates.  nt_frag_off<32>'s swizzle depends on
+    // (row >> 2) & 3 only, i.e. on lane & 15 (WM, WN1 and the 16-row steps are multiples of 16): fragment i sits 16 rows = 1024 B
+    // behind fragment 0.  As MI + NJ1 separately computed offsets hipcc kept 10 registers live through both products and, at the 168
+    // registers three waves per SIMD leave, spilled them: the product-2 loop reloaded three from scratch in EVERY chunk, each behind
+    // s_waitcnt vmcnt(0) in the middle of its fragment reads (round-4 .s).
+    static_assert(WM % 16 == 0 && WN1 % 16 == 0, "16-row fragment steps");
+    const int aoff0 = nt_frag_off<32>(wr * WM + (lane & 15), lane >> 4);
+    const int boff10 = A1_BYTES + nt_frag_off<32>(wc * WN1 + (lane & 15), lane >> 4);
 
     f32x4 acc[MI][NJ1];
 #pragma unroll
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
         const char* At = smem + cur * SLOT1;
         s16x8 bfr[NJ1], af[MI];
 #pragma unroll
-        for (int j = 0; j < NJ1; ++j) bfr[j] = nt_frag_at(At, boff1[j]);
+        for (int j = 0; j < NJ1; ++j) bfr[j] = nt_frag_at(At, boff10 + j * 1024);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = nt_frag_at(At, aoff[i]);
+        for (int i = 0; i < MI; ++i) af[i] = nt_frag_at(At, aoff0 + i * 1024);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers, the slot's reads retired, before the barrier
         XF_ACC(0);
         PP_FENCE();
@@ -361,14 +364,6 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
     if (late) { __builtin_amdgcn_s_barrier(); PP_FENCE(); }
 
     // ---- product 2: out = drop(P) V' in 256-column passes; wave tile WM x 64
-    int boff2[NJ2][2];
-#pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
-        const int r = wc * 64 + j * 16;
-        tn_frag_offs<128>(r & 127, lane, boff2[j][0], boff2[j][1]);
-        boff2[j][0] += (r >> 7) * 8192;
-        boff2[j][1] += (r >> 7) * 8192;
-    }
     f32x4 acc2[MI][NJ2];
     cur = 0;
     int cc = 0;
@@ -396,6 +391,21 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the V' fragment offsets are recomputed per pass from an opaque copy of the lane id: hoisted out of the pass loop they
+        // stayed live through every pass epilogue (the kernel's register peak at 168) and were spilled -- five scratch reloads at
+        // the top of EVERY chunk, each behind a vmcnt wait (round-4 .s)
+        int boff2[NJ2][2];
+        {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+#pragma unroll
+            for (int j = 0; j < NJ2; ++j) {
+                const int r = wc * 64 + j * 16;
+                tn_frag_offs<128>(r & 127, lane_o, boff2[j][0], boff2[j][1]);
+                boff2[j][0] += (r >> 7) * 8192;
+                boff2[j][1] += (r >> 7) * 8192;
+            }
+        }
         for (int c = 0; c < KC2; ++c, ++cc) {
             const char* Bt = smem + RING2 + cur * SLOT2;
             const char* Pc = smem + c * PCH;
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(768, 3) void xf1_kernel(XfArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ2; ++j) bfr[j] = tn_frag_at(Bt, boff2[j][0], boff2[j][1]);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = nt_frag_at(Pc, aoff[i]);
+            for (int i = 0; i < MI; ++i) af[i] = nt_frag_at(Pc, aoff0 + i * 1024);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             XF_ACC(0);
             PP_FENCE();
