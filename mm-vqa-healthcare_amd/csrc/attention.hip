@@ -272,6 +272,8 @@ DEVINL AttnBlock attn_block() {
 
 // DROP (attention-probability dropout) is a template parameter: a run-time test per score element would split the
 // unrolled softmax into 16 basic blocks and fence the MFMA / VALU interleave for the eval-mode instances too.
+// (the dropout instance at four waves per SIMD -- 128 registers, 7 spilled -- measured 711 vs 648 us at 577 x 577, B = 256: it stays at
+// the 150 registers / three waves hipcc gives it, round 4)
 template <int NQ, bool MASK, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, (NQ == 1 && !MASK && !BIAS && !CAUSAL && !DROP) ? 4 : 2) void attn_fwd_coop_kernel(AttnArgs a) {
     if (DROP) drop_resolve(a.drop);
