@@ -160,7 +160,8 @@ def main():
     from m3ae_amd.modules.objectives import build_vqa_targets
 
     torch.set_num_threads(host_cores())
-    log(f"rank {rank}/{world} on {dev}: building model")
+    ops.use_launch_stream()   # the whole run is issued on the library's high-priority stream (M3AE_LAUNCH_PRIORITY=normal: the default stream)
+    log(f"rank {rank}/{world} on {dev}: building model (launch stream priority {torch.cuda.current_stream().priority})")
     cfg = finetune_vqa_rad_config(compute_dtype="bf16", t5_model_name=args.t5)
     if args.head == "pretrain":  # configs[3]: MLM + MIM + ITM @384, 64 text tokens (task_pretrain_m3ae, roberta vocabulary)
         from m3ae_amd.config import compose
@@ -563,6 +564,7 @@ def main():
                              "step (string metrics, m3ae_t5_mm_encoder_input.py:252-261) is EXCLUDED"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hip_streams": 2 if getattr(model.m3ae if args.head == "t5" else model, "two_streams", False) else 1,
+                       "launch_stream_priority": torch.cuda.current_stream().priority,
                        "launch": graph_note,
                        "optimizer": ("AdamW bucket by bucket on its own stream under backward (%d of %d buckets issued before "
                                      "backward ended)" % (getattr(reducer, "updated_in_backward", 0), reducer.nb))

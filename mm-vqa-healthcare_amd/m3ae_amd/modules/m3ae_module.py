@@ -169,7 +169,9 @@ class M3AETransformerSS(_Base):
 
     def _side(self):
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()   # default priority (a high-priority side stream measured the same)
+            # default priority (a high-priority side stream measured the same in round 3; M3AE_SIDE_STREAM_PRIORITY: A/B runs only)
+            prio = os.environ.get("M3AE_SIDE_STREAM_PRIORITY")
+            self._side_stream = torch.cuda.Stream() if prio is None else torch.cuda.Stream(priority=int(prio))
             # gradients of directly-used leaves (e.g. the modality type embeddings) arrive from nodes of either stream: intended
             warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if warn_off is not None:

@@ -207,6 +207,18 @@ class Trainer:
         return (t[0] / t[1]).item()
 
     def fit(self):
+        """The training loop, issued on the library's high-priority launch stream (ops.launch_stream: the image half's kernels are
+        dispatched ahead of the text half's on the side stream); the caller's stream is current again when it returns."""
+        if not torch.cuda.is_available():
+            return self._fit()
+        prev = ops.use_launch_stream()
+        try:
+            return self._fit()
+        finally:
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(prev)
+
+    def _fit(self):
         P, cfg = self.plan, self.cfg
         gs = P["grad_steps"]
         self.model.train()

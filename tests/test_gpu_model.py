@@ -792,6 +792,39 @@ def test_two_stream_schedule_equals_the_single_stream_step(task):
     m.two_streams = type(m).two_streams
 
 
+def test_step_on_the_high_priority_launch_stream_equals_the_default_stream_step():
+    """bench.py and trainer.py issue the step on ops.launch_stream() (high priority: the image half's workgroups are dispatched ahead
+    of the text half's on the normal-priority side stream).  Same kernels, same seeds: forward bit-identical, gradients equal up to
+    the order of the fp32 atomics; the caller's stream is restored."""
+    from m3ae_amd import ops
+    cfg = finetune_vqa_rad_config(compute_dtype="bf16")
+    b = to_dev(synth.synthetic_batch(8, text_len=32, image_size=384, rank=0))
+    m = build(cfg, torch.bfloat16)
+    m.set_task()
+
+    def step():
+        m.train()
+        m.store.zero_grad()
+        ops.set_dropout_seed(11)
+        ret = m(b)
+        ret["vqa_loss"].backward()
+        torch.cuda.synchronize()
+        return ret["vqa_loss"].item(), m.store.grad.clone(), ret["multi_modal_cls_feats"].float().clone()
+
+    l0, g0, f0 = step()
+    prev = ops.use_launch_stream()
+    try:
+        assert torch.cuda.current_stream().priority == -1 and torch.cuda.current_stream() == ops.launch_stream()
+        for _ in range(3):
+            l1, g1, f1 = step()
+            assert abs(l1 - l0) <= 1e-6 * abs(l0) and torch.equal(f0, f1)
+            assert ((g1 - g0).double().norm() / g0.double().norm()).item() <= 1e-5
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev)
+    assert torch.cuda.current_stream() == prev
+
+
 def test_optimizer_in_backward_equals_the_step_after_backward():
     """`FlatGradReducer(update_in_backward=True)` without data parallelism (an opt-in of bench.py: --optimizer-in-backward): AdamW runs bucket by
     bucket on its own stream as backward completes the buckets.  Same kernels over the same ranges with the same
