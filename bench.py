@@ -140,18 +140,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    from m3ae_amd.ddp import rccl_group_options   # (imported before anything initialises HIP: m3ae_amd sets GPU_MAX_HW_QUEUES)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=rccl_group_options())
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if args.rehearse_ddp and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=rccl_group_options())
 
     from m3ae_amd import ops, synth
     from m3ae_amd.config import finetune_vqa_rad_config

@@ -36,6 +36,19 @@ import torch.distributed as dist
 from . import ops
 
 
+
+def rccl_group_options():
+    """Options for dist.init_process_group("nccl", pg_options=...): RCCL's streams at HIGH priority.  The step's launch stream is
+    high priority (ops.launch_stream): at normal priority the collectives' few workgroups would be dispatched only in the compute
+    kernels' tails and could surface at the end of backward.  None when this torch build has no such option."""
+    try:
+        from torch.distributed import ProcessGroupNCCL
+        opts = ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:  # noqa: BLE001
+        return None
+
 class FlatGradReducer:
     def __init__(self, store, bucket_bytes=64 << 20, group=None, overlap=True, collective=None, world=None,
                  tail_bytes=8 << 20, grad_dtype="fp32", update_in_backward=False):

@@ -288,7 +288,8 @@ def init_distributed():
     torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        from .ddp import rccl_group_options
+        dist.init_process_group("nccl", device_id=dev, pg_options=rccl_group_options())  # nccl == RCCL on ROCm; its streams at the launch stream's priority
     return rank, world, dev
 
 
