@@ -347,3 +347,30 @@ def test_input_pipeline_against_the_reference_dataset_classes(tmp_path, golden_d
         assert r["vqa_answer"] == [g["vqa_answer"][i]] and r["vqa_labels"] == [int(g["vqa_labels"][i])]
         assert r["vqa_scores"] == [float(g["vqa_scores"][i])] and r["answer_types"] == int(g["vqa_answer_types"][i])
         assert r["qid"] == int(g["vqa_qid"][i])
+
+
+def test_build_refuses_scratch_in_kernels_with_inline_asm_loads():
+    """m3ae_amd/build.py parses hipcc's kernel-resource-usage remarks: a kernel whose epilogue operands are loaded from inline asm
+    (gemm_nt_common.h: gload16_asm) must not use scratch memory -- a spill between such a load and its wait would save a register
+    whose load is still in flight.  The catch-all epilogue class (EPI_ANY = 5) keeps compiler-visible loads and may spill."""
+    import pytest
+    from m3ae_amd import build as B
+
+    def remarks(kernels):
+        out = []
+        for name, scratch in kernels:
+            out += [f"x.hip:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]",
+                    "x.hip:1:1: remark:     VGPRs: 253 [-Rpass-analysis=kernel-resource-usage]",
+                    f"x.hip:1:1: remark:     ScratchSize [bytes/lane]: {scratch} [-Rpass-analysis=kernel-resource-usage]"]
+        return "\n".join(out)
+
+    pp2 = "_ZN12_GLOBAL__N_118gemm_nt_pp2_kernelILi%dEEEvN3m3g8MfmaArgsE"
+    assert B.check_no_scratch("gemm_nt_pp2.hip", remarks([(pp2 % 0, 0), (pp2 % 6, 0), (pp2 % 5, 832)])) == 3
+    with pytest.raises(RuntimeError, match="scratch"):
+        B.check_no_scratch("gemm_nt_pp2.hip", remarks([(pp2 % 0, 0), (pp2 % 1, 16)]))
+    nt128 = "_ZN12_GLOBAL__N_119gemm_nt_bf16_kernelILi128ELi128ELi64ELi2ELi64ELi%dEEEvN3m3g8MfmaArgsE"
+    assert B.check_no_scratch("gemm_mfma.hip", remarks([(nt128 % 0, 0), (nt128 % 5, 52), ("_Z17gemm_tn_pp_kernelN3m3g8MfmaArgsE", 64)])) == 2
+    with pytest.raises(RuntimeError, match="scratch"):
+        B.check_no_scratch("gemm_mfma.hip", remarks([(nt128 % 3, 8)]))
+    with pytest.raises(RuntimeError, match="no kernel-resource-usage remarks"):
+        B.check_no_scratch("gemm_nt_pp2.hip", "nothing here")
