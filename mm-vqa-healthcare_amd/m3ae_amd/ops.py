@@ -25,7 +25,7 @@ SAVE_DACT = os.environ.get("M3AE_SAVE_DACT", "1") != "0"
 NT_NO_PERSISTENT = os.environ.get("M3AE_NT_NO_PERSISTENT", "0") == "1"   # (set by ddp.FlatGradReducer.attach; the env default is for A/B runs)
 # diagnostic per-call kernel selectors (m3ae_gemm_desc.launch_flags; -1 / 0 = by shape): tests compare kernel variants bit for
 # bit, tools time them; the product path never sets them
-GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = int(os.environ.get("M3AE_GEMM_NT_VARIANT", -1)), int(os.environ.get("M3AE_GEMM_TN_VARIANT", -1)), 0   # (env: A/B runs of tools)
+GEMM_NT_VARIANT, GEMM_TN_VARIANT, GEMM_COL_GROUP = int(os.environ.get("M3AE_GEMM_NT_VARIANT", -1)), int(os.environ.get("M3AE_GEMM_TN_VARIANT", -1)), int(os.environ.get("M3AE_GEMM_COL_GROUP", 0))   # (env: A/B runs of tools)
 
 
 ATTN_LEGACY = os.environ.get("M3AE_ATTN_LEGACY", "0") == "1"   # round-3 attention kernels (tests / tools compare the generations)
