@@ -30,6 +30,7 @@ last step (tests; DESIGN.md 7 states the exposed-communication prediction this i
 by <= ~1e-2 in relative L2 norm (stated tolerance, held by the two-virtual-rank GPU test; single elements whose gradient is
 rounding noise can differ by their whole value, which AdamW's m / sqrt(v) turns into a full +-lr step for those elements).
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -143,7 +144,7 @@ class FlatGradReducer:
 
     def attach(self):
         ops.grad_ready_hook = self.on_grad_ready if (self.world > 1 or self.update_in_backward) else None
-        if self.world > 1:
+        if self.world > 1 and os.environ.get("M3AE_DDP_KEEP_PERSISTENT") != "1":   # (the env: A/B runs of the rehearsal only)
             # RCCL's kernels run next to backward and hold some CUs: the persistent NT kernel (static tile lists, one
             # workgroup per CU) would wait for them with a whole tile list in hand; every GEMM descriptor issued while the
             # reducer is attached asks for the one-tile-per-workgroup launch (restored by detach())
