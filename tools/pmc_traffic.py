@@ -42,7 +42,7 @@ def main():
     for tot, n, c, rd, wr in sorted(rows, reverse=True)[:40]:
         print(f"{n[:100]:100s} {c:8d} {rd / 1e6:15.2f} {wr / 1e6:16.2f} {tot / 1e6:10.2f}")
     if pairs:   # tools/xattn_pair.py ran `pairs` forward layer pairs: bytes per pair over the kernels of the sub-block
-        sel = [r for r in rows if any(t in r[1] for t in ("xf1_kernel", "xg_kernel", "xattn_", "gemm_", "ln_fwd"))]
+        sel = [r for r in rows if any(t in r[1] for t in ("xf1_kernel", "xg_kernel", "xbuild_kernel", "xattn_", "gemm_", "ln_fwd"))]
         tot = sum((r[3] + r[4]) * r[2] for r in sel)
         print(f"\nfused cross-attention forward, one layer pair (both directions), fabric-side bytes: {tot / pairs / 1e9:.3f} GB "
               f"({sum(r[2] for r in sel) / pairs:.1f} launches per pair)")
