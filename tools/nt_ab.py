@@ -2,7 +2,7 @@
 (rounds x variants), min and median per variant; every variant's output is first compared bit for bit with variant 4 (the
 2-stage kernel with the same accumulation order).
 
-    B=256 VARS=8,10,11 ROUNDS=5 python tools/nt_ab.py [tag]
+    B=256 VARS=8,10 ROUNDS=5 python tools/nt_ab.py [tag]      (M=8192: other row counts; SHAPES=2304x768,...: a subset)
 """
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "mm-vqa-healthcare_amd"))
 import torch  # noqa: E402
 from m3ae_amd import ops  # noqa: E402
 
-VARS = tuple(int(v) for v in os.environ.get("VARS", "8,10,11").split(","))   # v + 100 * p: variant v with output-store policy p (1 plain, 2 nt, 3 sc1)
+VARS = tuple(int(v) for v in os.environ.get("VARS", "8,10").split(","))   # v + 100 * p: variant v with output-store policy p (1 plain, 2 nt, 3 sc1)
 ROUNDS = int(os.environ.get("ROUNDS", 5))
 ITERS = int(os.environ.get("ITERS", 10))
 SHAPES = os.environ.get("SHAPES", "")
